@@ -1,0 +1,112 @@
+"""Block-dict construction for the all-at-once KKT system (host side).
+
+Mirrors which ``(i, j)`` blocks exist and their coefficients in
+``Control.Instationary.linear_solve`` (``control/control.py:2889-2978``) and
+``Control.Stationary.linear_solve`` (``control/control.py:547-554``), with SciPy CSR
+matrices in place of UFL forms.  Dicts hold **all** ``n_row * n_col`` keys with
+``None`` for structural zeros, as ``MultiBlockSystem`` requires
+(``preconditioner/preconditioner.py:243-258``).
+
+Blocks that are the same Python object share storage on the device ("mode S");
+pass ``share=False`` to give every ``(i, j)`` block its own copy of the values
+("mode G", what the reference stores).
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import scipy.sparse as sp
+
+__all__ = ["instationary_blocks", "stationary_blocks"]
+
+
+def _csr(A):
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    return A
+
+
+def _own(A, share):
+    return A if share else A.copy()
+
+
+def stationary_blocks(M, K, beta):
+    """``control/control.py:547-554``: ``[[M, K^T], [K, -(1/beta) M]]``."""
+    M = _csr(M)
+    K = _csr(K)
+    return ({(0, 0): M}, {(0, 0): _csr(K.T)}, {(0, 0): K},
+            {(0, 0): _csr((-1.0 / beta) * M)})
+
+
+def instationary_blocks(M, K: Sequence, tau: float, beta: float, n_t: int,
+                        CN: bool, *, share: bool = True):
+    """Space-time KKT blocks.
+
+    ``K[i]`` is the forward-operator matrix at time level ``i`` (``D_v_i`` of
+    ``control/control.py:2903``); pass one matrix repeated for a time-invariant
+    operator.  Returns ``(block_00, block_01, block_10, block_11, m)`` with ``m`` the
+    number of blocks per variable (``n_t`` for BE, ``n_t - 1`` for CN).
+    """
+    M = _csr(M)
+    if not isinstance(K, (list, tuple)):
+        K = [K] * n_t
+    if len(K) != n_t:
+        raise ValueError("need one forward-operator matrix per time level")
+    K = [_csr(k) for k in K]
+    cache = {}
+
+    def comb(a, i, b, transpose=False):
+        """a * K_i (or its transpose) + b * M, cached so equal blocks are one object."""
+        key = (a, id(K[i]), b, transpose)
+        if share and key in cache:
+            return cache[key]
+        Ki = K[i].T if transpose else K[i]
+        A = _csr(a * Ki + b * M)
+        cache[key] = A
+        return A
+
+    def mass(c):
+        key = ("M", c)
+        if share and key in cache:
+            return cache[key]
+        A = _csr(c * M)
+        cache[key] = A
+        return A
+
+    if not CN:
+        m = n_t
+        b00 = {(i, j): None for i in range(m) for j in range(m)}
+        b01 = dict(b00)
+        b10 = dict(b00)
+        b11 = dict(b00)
+        for i in range(n_t):
+            # control/control.py:2907-2928 (rows 0..n_t-2) and 2960-2978 (last row)
+            if i < n_t - 1:
+                b00[(i, i)] = mass(tau)
+                b01[(i, i + 1)] = mass(-1.0)
+            b01[(i, i)] = comb(tau, i, 1.0, transpose=True)
+            b10[(i, i)] = comb(tau, i, 1.0)
+            if i >= 1:
+                b10[(i, i - 1)] = mass(-1.0)
+                b11[(i, i)] = mass(-tau / beta)
+        return b00, b01, b10, b11, m
+
+    m = n_t - 1
+    h = 0.5 * tau
+    b00 = {(i, j): None for i in range(m) for j in range(m)}
+    b01 = dict(b00)
+    b10 = dict(b00)
+    b11 = dict(b00)
+    for i in range(m):
+        # control/control.py:2938-2958; D_v_i at level i, D_v_i_plus at level i+1
+        if i >= 1:
+            b00[(i, i - 1)] = mass(h)
+            b10[(i, i - 1)] = comb(h, i, -1.0)
+        b00[(i, i)] = mass(h)
+        b01[(i, i)] = comb(h, i, 1.0, transpose=True)
+        b10[(i, i)] = comb(h, i + 1, 1.0)
+        b11[(i, i)] = mass(-h / beta)
+        if i + 1 < m:
+            b01[(i, i + 1)] = comb(h, i + 1, -1.0, transpose=True)
+            b11[(i, i + 1)] = mass(-h / beta)
+    return b00, b01, b10, b11, m

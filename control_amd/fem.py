@@ -1,0 +1,180 @@
+"""Host-side finite-element input generation (NumPy/SciPy, no Firedrake).
+
+The reference gets its spatial blocks from Firedrake ``assemble`` of UFL forms
+(``preconditioner/preconditioner.py:305-328``).  Firedrake is not available in
+this pipeline, so synthetic systems of the BASELINE.json shapes are produced
+here: the mass matrix ``M = int u w`` and the stiffness matrix
+``K = int grad u . grad w`` (the README's ``forw_diff_operator``,
+``README.md:31-32``) on structured meshes, as SciPy CSR with sorted int32
+column indices -- exactly what ``petscmat.getValuesCSR()`` would hand over.
+
+This module is input generation only.  It is shared by the product host layer
+(bench / smoke build their synthetic systems with it) and by the tests; it holds
+no solver arithmetic.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import scipy.sparse as sp
+
+__all__ = [
+    "SpatialDiscretisation",
+    "unit_square_p1",
+    "unit_cube_p1",
+    "unit_square_q2",
+    "rectangle_p1",
+]
+
+
+@dataclass
+class SpatialDiscretisation:
+    """One spatial function space: matrices, boundary dofs and dof coordinates."""
+
+    M: sp.csr_matrix          # mass matrix
+    K: sp.csr_matrix          # stiffness matrix (grad-grad)
+    coords: np.ndarray        # (N_x, dim) dof coordinates
+    boundary: np.ndarray      # int32 sorted dof indices on the whole boundary
+    name: str = ""
+
+    @property
+    def n_dofs(self) -> int:
+        return self.M.shape[0]
+
+
+def _canonical_csr(A: sp.spmatrix) -> sp.csr_matrix:
+    A = sp.csr_matrix(A)
+    A.sum_duplicates()
+    A.sort_indices()
+    A.indptr = A.indptr.astype(np.int32)
+    A.indices = A.indices.astype(np.int32)
+    A.data = np.ascontiguousarray(A.data, dtype=np.float64)
+    return A
+
+
+def _p1_simplex_assemble(coords: np.ndarray, cells: np.ndarray):
+    """Mass and stiffness for P1 on simplices (dim 2 or 3), fully vectorised."""
+    n_nodes, dim = coords.shape
+    nv = dim + 1
+    X = coords[cells]                                   # (nc, nv, dim)
+    # barycentric gradients: rows of inv([1 x]) without the constant row
+    A = np.concatenate([np.ones((len(cells), nv, 1)), X], axis=2)  # (nc,nv,nv)
+    Ainv = np.linalg.inv(A)                             # columns = coefficients
+    grads = np.transpose(Ainv[:, 1:, :], (0, 2, 1))     # (nc, nv, dim)
+    fact = {2: 2.0, 3: 6.0}[dim]
+    vol = np.abs(np.linalg.det(A)) / fact               # (nc,)
+    Ke = np.einsum("cid,cjd->cij", grads, grads) * vol[:, None, None]
+    Mref = (np.ones((nv, nv)) + np.eye(nv)) / ((dim + 1.0) * (dim + 2.0))
+    Me = vol[:, None, None] * Mref[None, :, :]
+    rows = np.repeat(cells, nv, axis=1).ravel()
+    cols = np.tile(cells, (1, nv)).ravel()
+    M = sp.coo_matrix((Me.ravel(), (rows, cols)), shape=(n_nodes, n_nodes))
+    K = sp.coo_matrix((Ke.ravel(), (rows, cols)), shape=(n_nodes, n_nodes))
+    return _canonical_csr(M), _canonical_csr(K)
+
+
+def rectangle_p1(nx: int, ny: int, lx: float = 1.0, ly: float = 1.0,
+                 diagonal: str = "right") -> SpatialDiscretisation:
+    """P1 on a structured triangulation of ``[0,lx] x [0,ly]``.
+
+    Node ``(i, j)`` has index ``j * (nx + 1) + i``.  ``diagonal="right"`` cuts every
+    cell from its lower-left to its upper-right corner.
+    """
+    xs = np.linspace(0.0, lx, nx + 1)
+    ys = np.linspace(0.0, ly, ny + 1)
+    XX, YY = np.meshgrid(xs, ys, indexing="xy")
+    coords = np.stack([XX.ravel(), YY.ravel()], axis=1)
+    ii, jj = np.meshgrid(np.arange(nx), np.arange(ny), indexing="xy")
+    n00 = (jj * (nx + 1) + ii).ravel()
+    n10 = n00 + 1
+    n01 = n00 + (nx + 1)
+    n11 = n01 + 1
+    if diagonal == "right":
+        cells = np.concatenate([np.stack([n00, n10, n11], 1),
+                                np.stack([n00, n11, n01], 1)], 0)
+    elif diagonal == "left":
+        cells = np.concatenate([np.stack([n00, n10, n01], 1),
+                                np.stack([n10, n11, n01], 1)], 0)
+    else:
+        raise ValueError("diagonal must be 'right' or 'left'")
+    M, K = _p1_simplex_assemble(coords, cells)
+    onb = ((coords[:, 0] == xs[0]) | (coords[:, 0] == xs[-1])
+           | (coords[:, 1] == ys[0]) | (coords[:, 1] == ys[-1]))
+    return SpatialDiscretisation(M, K, coords,
+                                 np.flatnonzero(onb).astype(np.int32),
+                                 f"P1 {nx}x{ny}")
+
+
+def unit_square_p1(n: int, diagonal: str = "right") -> SpatialDiscretisation:
+    """``UnitSquareMesh(n, n)`` with ``FunctionSpace(mesh, "Lagrange", 1)``."""
+    return rectangle_p1(n, n, 1.0, 1.0, diagonal)
+
+
+def unit_cube_p1(n: int) -> SpatialDiscretisation:
+    """P1 on the 6-tetrahedra-per-cube (Kuhn) subdivision of the unit cube."""
+    xs = np.linspace(0.0, 1.0, n + 1)
+    ZZ, YY, XX = np.meshgrid(xs, xs, xs, indexing="ij")
+    coords = np.stack([XX.ravel(), YY.ravel(), ZZ.ravel()], axis=1)
+    np1 = n + 1
+
+    def nid(i, j, k):
+        return (k * np1 + j) * np1 + i
+
+    kk, jj, ii = np.meshgrid(np.arange(n), np.arange(n), np.arange(n),
+                             indexing="ij")
+    ii, jj, kk = ii.ravel(), jj.ravel(), kk.ravel()
+    cells = []
+    # Kuhn: one tetrahedron per permutation of the axes, all sharing the main diagonal
+    import itertools
+    for perm in itertools.permutations(range(3)):
+        off = np.zeros(3, dtype=np.int64)
+        verts = [nid(ii, jj, kk)]
+        for ax in perm:
+            off = off.copy()
+            off[ax] = 1
+            verts.append(nid(ii + off[0], jj + off[1], kk + off[2]))
+        cells.append(np.stack(verts, 1))
+    cells = np.concatenate(cells, 0)
+    M, K = _p1_simplex_assemble(coords, cells)
+    onb = np.zeros(len(coords), dtype=bool)
+    for d in range(3):
+        onb |= (coords[:, d] == 0.0) | (coords[:, d] == 1.0)
+    return SpatialDiscretisation(M, K, coords,
+                                 np.flatnonzero(onb).astype(np.int32),
+                                 f"P1 {n}^3")
+
+
+def _p2_1d(n: int, length: float):
+    """1-D quadratic Lagrange mass and stiffness on ``n`` elements (2n+1 nodes)."""
+    h = length / n
+    Me = h / 30.0 * np.array([[4.0, 2.0, -1.0], [2.0, 16.0, 2.0], [-1.0, 2.0, 4.0]])
+    Ke = 1.0 / (3.0 * h) * np.array([[7.0, -8.0, 1.0], [-8.0, 16.0, -8.0],
+                                     [1.0, -8.0, 7.0]])
+    nn = 2 * n + 1
+    M = sp.lil_matrix((nn, nn))
+    K = sp.lil_matrix((nn, nn))
+    for e in range(n):
+        idx = np.array([2 * e, 2 * e + 1, 2 * e + 2])
+        M[np.ix_(idx, idx)] += Me
+        K[np.ix_(idx, idx)] += Ke
+    return sp.csr_matrix(M), sp.csr_matrix(K), np.linspace(0.0, length, nn)
+
+
+def unit_square_q2(n: int) -> SpatialDiscretisation:
+    """Q2 on ``UnitSquareMesh(n, n, quadrilateral=True)`` (tensor-product form).
+
+    This is the space of the reference's known-answer tests
+    (``test/test_control.py:1244-1247``).  Dof ``(i, j)`` of the ``(2n+1)^2`` grid
+    has index ``j * (2n + 1) + i``.
+    """
+    M1, K1, xs = _p2_1d(n, 1.0)
+    M = sp.kron(M1, M1)
+    K = sp.kron(M1, K1) + sp.kron(K1, M1)
+    XX, YY = np.meshgrid(xs, xs, indexing="xy")
+    coords = np.stack([XX.ravel(), YY.ravel()], axis=1)
+    onb = ((coords[:, 0] == 0.0) | (coords[:, 0] == 1.0)
+           | (coords[:, 1] == 0.0) | (coords[:, 1] == 1.0))
+    return SpatialDiscretisation(_canonical_csr(M), _canonical_csr(K), coords,
+                                 np.flatnonzero(onb).astype(np.int32),
+                                 f"Q2 {n}x{n}")

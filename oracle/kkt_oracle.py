@@ -1,0 +1,677 @@
+"""CPU oracle (NumPy/SciPy) for the all-at-once KKT hot path.  TEST INFRASTRUCTURE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module; the product (``control_amd``) never does.
+
+It restates, function by function, what the reference computes on the path
+``MultiBlockSystem.solve()`` (all citations relative to ``/root/reference``):
+
+* ``OracleSystem.mult``       <- ``preconditioner/preconditioner.py:375-543``
+* ``OracleSystem.pc_apply``   <- ``preconditioner/preconditioner.py:562-656``
+* ``OracleSystem.solve``      <- ``preconditioner/preconditioner.py:658-786``
+* nullspace classes           <- ``preconditioner/preconditioner.py:75-213``
+* ``apply_T_1/2`` (+inverses) <- ``preconditioner/preconditioner.py:33-60``,
+                                 ``control/control.py:26-96``
+* ``pc_instationary_BE/CN``   <- ``control/control.py:2191-2438`` / ``1995-2189``
+* ``pc_stationary``           <- ``control/control.py:356-448``
+
+Third-party arithmetic (PETSc ``KSP`` gmres/fgmres/chebyshev, ``PC`` jacobi;
+petsc4py, version unpinned by the reference, absent from this image) is restated from
+the published algorithms: ``gmres``/``fgmres`` follow ``KSPSolve_GMRES`` /
+``KSPSolve_FGMRES`` (classical Gram-Schmidt without refinement, Givens rotations,
+``KSPConvergedDefault`` with the right-hand-side norm as reference because the
+reference sets ``setInitialGuessNonzero(True)``, ``preconditioner.py:743``);
+``chebyshev_jacobi`` follows ``KSPSolve_Chebyshev`` (first kind, fixed bounds, zero
+initial guess, exactly ``its`` steps).  hypre BoomerAMG sub-solves are replaced, as
+BASELINE.json's ``north_star`` prescribes, by the same Jacobi-Chebyshev iteration with
+a stated degree and stated bounds.
+
+PARITY PINNING: the reference's own known-answer tests (``test/test_control.py:26-119``,
+``1243-1444``, ``1447-1655``) pin the operator and the converged solution; this oracle is
+checked against restatements of them in ``tests/test_oracle_kat.py``.  Krylov iterates
+and iteration counts are pinned by NO reference test or fixture: for those, parity is
+"unpinned" (oracle-vs-GPU agreement only).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+import scipy.sparse as sp
+
+# --------------------------------------------------------------------------- T ops
+
+
+def apply_T_1(x):
+    """``new_i = old_i + old_{i+1}`` (``preconditioner.py:33-45``).  x: (n, nx)."""
+    y = x.copy()
+    y[:-1] += x[1:]
+    return y
+
+
+def apply_T_2(x):
+    """``new_i = old_i + old_{i-1}`` (``preconditioner.py:48-60``)."""
+    y = x.copy()
+    y[1:] += x[:-1]
+    return y
+
+
+def apply_T_1_inv(x):
+    """Sequential: ``for i=n-2..0: x_i -= x_{i+1}`` (``control.py:63-78``)."""
+    y = x.copy()
+    for i in range(y.shape[0] - 2, -1, -1):
+        y[i] -= y[i + 1]
+    return y
+
+
+def apply_T_2_inv(x):
+    """Sequential: ``for i=1..n-1: x_i -= x_{i-1}`` (``control.py:81-96``)."""
+    y = x.copy()
+    for i in range(1, y.shape[0]):
+        y[i] -= y[i - 1]
+    return y
+
+
+# ---------------------------------------------------------------------- nullspaces
+
+
+class NoneNullspace:
+    """``preconditioner.py:119-130``."""
+
+    def lhs_right(self, x):
+        pass
+
+    def lhs_left(self, y):
+        pass
+
+    def extended_correct_lhs(self, x, y):
+        pass
+
+    def pc_extended_correct_soln(self, u, b):
+        pass
+
+
+class DirichletBCNullspace(NoneNullspace):
+    """``preconditioner.py:158-197``: zero the listed dofs; add ``alpha * x`` there."""
+
+    def __init__(self, nodes, *, alpha=1.0):
+        self.nodes = np.asarray(nodes, dtype=np.int64)
+        self.alpha = alpha
+
+    def lhs_right(self, x):
+        x[self.nodes] = 0.0
+
+    def lhs_left(self, y):
+        y[self.nodes] = 0.0
+
+    def extended_correct_lhs(self, x, y):
+        y[self.nodes] += self.alpha * x[self.nodes]
+
+    def pc_extended_correct_soln(self, u, b):
+        u[self.nodes] += 1.0 * b[self.nodes]
+
+
+class ConstantNullspace(NoneNullspace):
+    """``preconditioner.py:133-155``: shift by the arithmetic mean."""
+
+    def __init__(self, *, alpha=1.0):
+        self.alpha = alpha
+
+    @staticmethod
+    def _correct(x, y, alpha):
+        y += alpha * x.sum() / float(x.size)
+
+    def lhs_right(self, x):
+        self._correct(x, x, -1.0)
+
+    def lhs_left(self, y):
+        self._correct(y, y, -1.0)
+
+    def extended_correct_lhs(self, x, y):
+        self._correct(x, y, self.alpha)
+
+    def pc_extended_correct_soln(self, u, b):
+        self._correct(b, u, 1.0)
+
+
+class FullNullspace(NoneNullspace):
+    """``preconditioner.py:200-213``."""
+
+    def lhs_right(self, x):
+        x[:] = 0.0
+
+    def lhs_left(self, y):
+        y[:] = 0.0
+
+    def extended_correct_lhs(self, x, y):
+        y[:] = x
+
+    def pc_extended_correct_soln(self, u, b):
+        u[:] = b
+
+
+# ------------------------------------------------------------------- Krylov (PETSc)
+
+CONVERGED_RTOL = 2
+CONVERGED_ATOL = 3
+CONVERGED_HAPPY_BREAKDOWN = 5
+DIVERGED_ITS = -3
+DIVERGED_DTOL = -4
+DIVERGED_BREAKDOWN = -5
+DIVERGED_NANORINF = -9
+
+
+@dataclass
+class KSPResult:
+    """What the reference reads off the returned KSP (``preconditioner.py:786``)."""
+    reason: int = 0
+    its: int = 0
+    rnorm: float = 0.0
+    history: list = field(default_factory=list)
+
+    def getConvergedReason(self):
+        return self.reason
+
+    def getIterationNumber(self):
+        return self.its
+
+    def getResidualNorm(self):
+        return self.rnorm
+
+
+class _ConvergedDefault:
+    """``KSPConvergedDefault`` with the RHS norm as ``rnorm0`` (nonzero initial guess)."""
+
+    def __init__(self, rtol, atol, divtol, rnorm0):
+        self.atol = atol
+        self.divtol = divtol
+        self.rnorm0 = rnorm0
+        self.ttol = max(rtol * rnorm0, atol)
+
+    def __call__(self, rnorm):
+        if not np.isfinite(rnorm):
+            return DIVERGED_NANORINF
+        if rnorm <= self.ttol:
+            return CONVERGED_ATOL if rnorm < self.atol else CONVERGED_RTOL
+        if rnorm >= self.divtol * self.rnorm0:
+            return DIVERGED_DTOL
+        return 0
+
+
+def _gmres_driver(A, B, b, x, *, restart, rtol, atol, divtol, max_it, flexible,
+                  right, monitor=None):
+    """GMRES(m) / FGMRES(m), structured like ``KSPSolve_GMRES`` + ``KSPGMRESCycle``.
+
+    left  (gmres default):  Krylov on B A, monitored norm ||B r||.
+    right (fgmres, or gmres with pc_side right): Krylov on A B, monitored norm ||r||.
+    """
+    n = b.size
+    res = KSPResult()
+    # KSPConvergedDefault at it == 0 with a nonzero guess: norm of the (preconditioned) rhs
+    rnorm0 = np.linalg.norm(b) if right else np.linalg.norm(B(b))
+    conv = _ConvergedDefault(rtol, atol, divtol, rnorm0)
+    haptol = 1.0e-30
+    its = 0
+    m = restart
+    V = np.zeros((m + 1, n))
+    Z = np.zeros((m, n)) if flexible else None
+    H = np.zeros((m + 1, m))
+    cc = np.zeros(m)
+    ss = np.zeros(m)
+    grs = np.zeros(m + 1)
+    reason = 0
+    while True:
+        # KSPInitialResidual
+        r = b - A(x)
+        V[0] = r if right else B(r)
+        rn = np.linalg.norm(V[0])
+        res.history.append(rn)
+        if monitor is not None:
+            monitor(its, rn)
+        res.rnorm = rn
+        if rn == 0.0:
+            reason = CONVERGED_ATOL
+            break
+        V[0] /= rn
+        grs[:] = 0.0
+        grs[0] = rn
+        reason = conv(rn)
+        it = 0
+        H[:] = 0.0
+        while not reason and it < m and its < max_it:
+            if it:
+                res.history.append(rn)
+                if monitor is not None:
+                    monitor(its, rn)
+            if right:
+                z = B(V[it])
+                if flexible:
+                    Z[it] = z
+                w = A(z)
+            else:
+                w = B(A(V[it]))
+            # classical Gram-Schmidt, no refinement (VecMDot, VecMAXPY)
+            h = V[:it + 1] @ w
+            w = w - h @ V[:it + 1]
+            H[:it + 1, it] = h
+            tt = np.linalg.norm(w)
+            hapbnd = min(abs(tt / grs[it]), haptol)
+            hapend = tt < hapbnd
+            if not hapend:
+                V[it + 1] = w / tt
+            H[it + 1, it] = tt
+            # KSPGMRESUpdateHessenberg
+            for j in range(it):
+                t = H[j, it]
+                H[j, it] = cc[j] * t + ss[j] * H[j + 1, it]
+                H[j + 1, it] = cc[j] * H[j + 1, it] - ss[j] * t
+            if not hapend:
+                t = np.sqrt(H[it, it] * H[it, it] + H[it + 1, it] * H[it + 1, it])
+                if t == 0.0:
+                    reason = DIVERGED_BREAKDOWN
+                    break
+                cc[it] = H[it, it] / t
+                ss[it] = H[it + 1, it] / t
+                grs[it + 1] = -(ss[it] * grs[it])
+                grs[it] = cc[it] * grs[it]
+                H[it, it] = cc[it] * H[it, it] + ss[it] * H[it + 1, it]
+                rn = abs(grs[it + 1])
+            else:
+                rn = 0.0
+            it += 1
+            its += 1
+            res.rnorm = rn
+            reason = conv(rn)
+            if hapend and not reason:
+                reason = DIVERGED_BREAKDOWN
+        if it and (reason or its >= max_it):
+            res.history.append(rn)
+            if monitor is not None:
+                monitor(its, rn)
+        # KSPGMRESBuildSoln
+        if it > 0:
+            y = np.zeros(it)
+            for k in range(it - 1, -1, -1):
+                y[k] = (grs[k] - H[k, k + 1:it] @ y[k + 1:]) / H[k, k]
+            if flexible:
+                x += y @ Z[:it]
+            elif right:
+                x += B(y @ V[:it])
+            else:
+                x += y @ V[:it]
+        if reason:
+            break
+        if its >= max_it:
+            reason = DIVERGED_ITS
+            break
+    res.reason = reason
+    res.its = its
+    return res
+
+
+def gmres(A, B, b, x, **kw):
+    kw.setdefault("right", False)
+    return _gmres_driver(A, B, b, x, flexible=False, **kw)
+
+
+def fgmres(A, B, b, x, **kw):
+    kw.pop("right", None)
+    return _gmres_driver(A, B, b, x, flexible=True, right=True, **kw)
+
+
+def chebyshev_jacobi(A, dinv, b, emin, emax, its):
+    """``KSPSolve_Chebyshev`` (first kind) with ``PCJACOBI``, zero guess, ``its`` steps.
+
+    Options of the reference: ``control/control.py:1973-1982`` (``ksp_max_it 20``,
+    ``rtol = atol = 0``, fixed eigenvalue bounds, no estimation).
+    """
+    scale = 2.0 / (emax + emin)
+    alpha = 1.0 - scale * emin
+    mu = 1.0 / alpha
+    omegaprod = 2.0 / alpha
+    c_km1 = 1.0
+    c_k = mu
+    p_km1 = np.zeros_like(b)
+    # zero guess: r = b; p_k = scale * B^-1 r + p_km1
+    p_k = scale * (dinv * b) + p_km1
+    for _ in range(1, its):
+        c_kp1 = 2.0 * mu * c_k - c_km1
+        omega = omegaprod * c_k / c_kp1
+        r = b - A @ p_k
+        z = dinv * r
+        # VecAXPBYPCZ(p_kp1, 1-omega, omega, scale*omega, p_km1, p_k)
+        p_kp1 = (1.0 - omega) * p_km1 + omega * p_k + (scale * omega) * z
+        p_km1, p_k = p_k, p_kp1
+        c_km1, c_k = c_k, c_kp1
+    return p_k
+
+
+# ----------------------------------------------------------------------- the system
+
+
+def _as_blocks(a, n, nx):
+    a = np.asarray(a, dtype=np.float64)
+    return a.reshape(n, nx)
+
+
+class OracleSystem:
+    """Restatement of ``MultiBlockSystem`` (``preconditioner.py:216-786``) on SciPy CSR.
+
+    Vectors are NumPy arrays of shape ``(n_blocks, nx)``; the flat KKT vector is the
+    ``n_blocks_00`` blocks of variable 0 followed by the ``n_blocks_11`` blocks of
+    variable 1 (``preconditioner.py:286-287``).
+    """
+
+    def __init__(self, nx0, nx1, block_00, block_01, block_10, block_11, *,
+                 n_blocks_00=1, n_blocks_11=1, sub_n_blocks_00_0=None,
+                 sub_n_blocks_11_0=None, nullspace_0=None, nullspace_1=None,
+                 CN=False):
+        n0, n1 = n_blocks_00, n_blocks_11
+        if nullspace_0 is None:
+            nullspace_0 = tuple(NoneNullspace() for _ in range(n0))
+        if nullspace_1 is None:
+            nullspace_1 = tuple(NoneNullspace() for _ in range(n1))
+        for blk, nr, nc in ((block_00, n0, n0), (block_01, n0, n1),
+                            (block_10, n1, n0), (block_11, n1, n1)):
+            if len(blk) != nr * nc:
+                raise ValueError("Unexpected dimension of blocks")
+        self.nx0, self.nx1, self.n0, self.n1 = nx0, nx1, n0, n1
+        self.blocks = (block_00, block_01, block_10, block_11)
+        self.nullspaces = tuple(nullspace_0) + tuple(nullspace_1)
+        self.sub00 = sub_n_blocks_00_0
+        self.sub11 = sub_n_blocks_11_0
+        self.CN = CN
+        self.N = n0 * nx0 + n1 * nx1
+
+    # -- flat <-> blocks
+    def split(self, x):
+        k = self.n0 * self.nx0
+        return (x[:k].reshape(self.n0, self.nx0),
+                x[k:].reshape(self.n1, self.nx1))
+
+    def join(self, a, b):
+        return np.concatenate([np.ravel(a), np.ravel(b)])
+
+    # -- preconditioner.py:375-543
+    def mult(self, x):
+        x0, x1 = self.split(np.asarray(x, dtype=np.float64))
+        n0, n1 = self.n0, self.n1
+        xc0 = x0.copy()
+        xc1 = x1.copy()
+        for i in range(n0):
+            self.nullspaces[i].lhs_right(xc0[i])
+        for i in range(n1):
+            self.nullspaces[n0 + i].lhs_right(xc1[i])
+        y0 = np.zeros_like(x0)
+        y1 = np.zeros_like(x1)
+        b00, b01, b10, b11 = self.blocks
+        for (i, j), A in b00.items():
+            if A is not None:
+                y0[i] += A @ xc0[j]
+        for (i, j), A in b01.items():
+            if A is not None:
+                y0[i] += A @ xc1[j]
+        for (i, j), A in b10.items():
+            if A is not None:
+                y1[i] += A @ xc0[j]
+        for (i, j), A in b11.items():
+            if A is not None:
+                y1[i] += A @ xc1[j]
+        if self.CN:
+            if self.sub00 is None and self.sub11 is None:
+                y0 = apply_T_1(y0)
+                y1 = apply_T_2(y1)
+            else:
+                s0, s1 = self.sub00, self.sub11
+                y0 = np.concatenate([apply_T_1(y0[:s0]), apply_T_2(y0[s0:])])
+                y1 = np.concatenate([apply_T_2(y1[:s1]), apply_T_1(y1[s1:])])
+        for i in range(n0):
+            ns = self.nullspaces[i]
+            ns.lhs_left(y0[i])
+            ns.extended_correct_lhs(x0[i], y0[i])
+        for i in range(n1):
+            ns = self.nullspaces[n0 + i]
+            ns.lhs_left(y1[i])
+            ns.extended_correct_lhs(x1[i], y1[i])
+        return self.join(y0, y1)
+
+    # -- preconditioner.py:562-656
+    def pc_apply(self, pc_fn, x):
+        b0, b1 = self.split(np.asarray(x, dtype=np.float64))
+        n0, n1 = self.n0, self.n1
+        b0c = b0.copy()
+        b1c = b1.copy()
+        for i in range(n0):
+            self.nullspaces[i].lhs_left(b0c[i])
+        for i in range(n1):
+            self.nullspaces[n0 + i].lhs_left(b1c[i])
+        u0 = np.zeros_like(b0)
+        u1 = np.zeros_like(b1)
+        pc_fn(u0, u1, b0c, b1c)
+        for i in range(n0):
+            ns = self.nullspaces[i]
+            ns.lhs_right(u0[i])
+            ns.pc_extended_correct_soln(u0[i], b0[i])
+        for i in range(n1):
+            ns = self.nullspaces[n0 + i]
+            ns.lhs_right(u1[i])
+            ns.pc_extended_correct_soln(u1[i], b1[i])
+        return self.join(u0, u1)
+
+    # -- preconditioner.py:337-345, 658-786
+    def solve(self, u_0, u_1, b_0, b_1, *, solver_parameters=None, pc_fn=None,
+              monitor=None):
+        if solver_parameters is None:
+            solver_parameters = {}
+        if pc_fn is None:
+            def pc_fn(u_0, u_1, b_0, b_1):
+                u_0[:] = b_0
+                u_1[:] = b_1
+        n0, n1 = self.n0, self.n1
+        U0 = _as_blocks(u_0, n0, self.nx0)
+        U1 = _as_blocks(u_1, n1, self.nx1)
+        u0 = U0.copy()
+        u1 = U1.copy()
+        b0 = _as_blocks(b_0, n0, self.nx0).copy()
+        b1 = _as_blocks(b_1, n1, self.nx1).copy()
+        for i in range(n0):
+            self.nullspaces[i].lhs_right(u0[i])      # correct_soln
+            self.nullspaces[i].lhs_left(b0[i])       # correct_rhs
+        for i in range(n1):
+            self.nullspaces[n0 + i].lhs_right(u1[i])
+            self.nullspaces[n0 + i].lhs_left(b1[i])
+        u = self.join(u0, u1)
+        b = self.join(b0, b1)
+        sp_ = solver_parameters
+        ksp_type = sp_.get("linear_solver", "fgmres")
+        kw = dict(restart=sp_.get("gmres_restart", 30),
+                  rtol=sp_["relative_tolerance"], atol=sp_["absolute_tolerance"],
+                  divtol=sp_.get("divergence limit", None) or 1.0e4,
+                  max_it=sp_.get("maximum_iterations", 1000), monitor=monitor)
+        A = self.mult
+
+        def B(v):
+            return self.pc_apply(pc_fn, v)
+
+        if ksp_type == "gmres":
+            res = gmres(A, B, b, u, right=(sp_.get("pc_side", "left") == "right"), **kw)
+        elif ksp_type == "fgmres":
+            res = fgmres(A, B, b, u, **kw)
+        else:
+            raise ValueError(f"oracle restates gmres and fgmres only, not {ksp_type}")
+        u0, u1 = self.split(u)
+        for i in range(n0):
+            self.nullspaces[i].lhs_right(u0[i])
+        for i in range(n1):
+            self.nullspaces[n0 + i].lhs_right(u1[i])
+        if not sp_.get("preconditioner", False) and res.reason <= 0:
+            raise RuntimeError("Solver failed to converge")
+        U0[:] = u0
+        U1[:] = u1
+        return res
+
+
+# ---------------------------------------------------------- built-in preconditioners
+
+
+def assemble_with_bcs(A, nodes):
+    """Firedrake ``assemble(form, bcs=...)``: bc rows/cols zeroed, unit diagonal."""
+    A = sp.csr_matrix(A, copy=True)
+    n = A.shape[0]
+    keep = np.ones(n)
+    keep[nodes] = 0.0
+    Dk = sp.diags(keep)
+    At = Dk @ A @ Dk + sp.diags(1.0 - keep)
+    At = sp.csr_matrix(At)
+    At.sort_indices()
+    return At
+
+
+@dataclass
+class ChebSpec:
+    """A Jacobi-Chebyshev inner solve: ``its`` steps on ``[emin, emax]``.
+
+    ``its == 0`` means a single Jacobi application (the reference's ``preonly`` +
+    ``jacobi`` branch, ``control/control.py:1984-1991``).
+    """
+    its: int
+    emin: float
+    emax: float
+
+
+def _inner_solve(At, spec, rhs):
+    dinv = 1.0 / At.diagonal()
+    if spec.its == 0:
+        return dinv * rhs
+    return chebyshev_jacobi(At, dinv, rhs, spec.emin, spec.emax, spec.its)
+
+
+def _bc(v, nodes):
+    v[nodes] = 0.0
+    return v
+
+
+def pc_stationary(M, D_v, D_zeta, beta, nodes, mass_spec, schur_spec):
+    """``Stationary.construct_pc`` (``control/control.py:351-450``)."""
+    Mt = assemble_with_bcs(M, nodes)
+    S1 = assemble_with_bcs(D_v + (1.0 / beta**0.5) * M, nodes)
+    S2 = assemble_with_bcs(D_zeta + (1.0 / beta**0.5) * M, nodes)
+
+    def pc_linear(u_0, u_1, b_0, b_1):
+        u_0[0] = _inner_solve(Mt, mass_spec, b_0[0])
+        b = D_v @ u_0[0] - b_1[0]
+        _bc(b, nodes)
+        u_1[0] = _inner_solve(S1, schur_spec, b)
+        b = M @ u_1[0]
+        _bc(b, nodes)
+        u_1[0] = _inner_solve(S2, schur_spec, b)
+    return pc_linear
+
+
+def pc_instationary_BE(M, block_01, block_10, n_t, tau, beta, nodes, mass_spec,
+                       schur_spec, epsilon=1.0e-3):
+    """BE branch of ``Instationary.construct_pc`` (``control/control.py:2191-2438``)."""
+    Mt = assemble_with_bcs(M, nodes)
+    shift = tau / beta**0.5
+
+    def solve(A, rhs):
+        return _inner_solve(assemble_with_bcs(A, nodes), schur_spec, rhs)
+
+    def pc_linear(u_0, u_1, b_0, b_1):
+        # (1,1)-block, control.py:2193-2206
+        for i in range(n_t):
+            u_0[i] = _inner_solve(Mt, mass_spec, b_0[i].copy())
+            u_0[i] *= 1.0 / tau
+        u_0[n_t - 1] *= 1.0 / epsilon
+        # b = D_v u_0 - b_1, control.py:2208-2237
+        b = np.zeros_like(u_0)
+        b[0] = block_10[(0, 0)] @ u_0[0]
+        b[0] -= b_1[0]
+        _bc(b[0], nodes)
+        for i in range(1, n_t):
+            t = block_10[(i, i - 1)] @ u_0[i - 1]
+            b[i] = block_10[(i, i)] @ u_0[i]
+            b[i] += t
+            b[i] -= b_1[i]
+            _bc(b[i], nodes)
+        # forward sweep, control.py:2241-2327
+        u_1[0] = solve(block_10[(0, 0)], b[0])
+        for i in range(1, n_t - 1):
+            b[i] -= block_10[(i, i - 1)] @ u_1[i - 1]
+            _bc(b[i], nodes)
+            u_1[i] = solve(block_10[(i, i)] + shift * M, b[i])
+        b[n_t - 1] -= block_10[(n_t - 1, n_t - 2)] @ u_1[n_t - 2]
+        _bc(b[n_t - 1], nodes)
+        u_1[n_t - 1] = solve(block_10[(n_t - 1, n_t - 1)]
+                             + (epsilon**0.5) * shift * M, b[n_t - 1])
+        # b = tau M u_1, control.py:2330-2350
+        b = np.zeros_like(u_0)
+        for i in range(n_t - 1):
+            b[i] = (M @ u_1[i]) * tau
+            _bc(b[i], nodes)
+        b[n_t - 1] = (M @ u_1[n_t - 1]) * (epsilon * tau)
+        _bc(b[n_t - 1], nodes)
+        # backward sweep, control.py:2353-2437
+        u_1[n_t - 1] = solve(block_01[(n_t - 1, n_t - 1)]
+                             + (epsilon**0.5) * shift * M, b[n_t - 1])
+        for i in range(n_t - 2, 0, -1):
+            b[i] -= block_01[(i, i + 1)] @ u_1[i + 1]
+            _bc(b[i], nodes)
+            u_1[i] = solve(block_01[(i, i)] + shift * M, b[i])
+        b[0] -= block_01[(0, 1)] @ u_1[1]
+        _bc(b[0], nodes)
+        u_1[0] = solve(block_01[(0, 0)], b[0])
+    return pc_linear
+
+
+def pc_instationary_CN(M, block_01, block_10, n_t, tau, beta, nodes, mass_spec,
+                       schur_spec):
+    """CN branch of ``Instationary.construct_pc`` (``control/control.py:1995-2189``)."""
+    m = n_t - 1
+    Mt = assemble_with_bcs(M, nodes)
+    my_const = 0.5 * tau / beta**0.5
+
+    def solve(A, rhs):
+        return _inner_solve(assemble_with_bcs(A, nodes), schur_spec, rhs)
+
+    def pc_linear(u_0, u_1, b_0, b_1):
+        # (1,1)-block, control.py:1997-2014
+        b_0_help = apply_T_1_inv(b_0)
+        for i in range(m):
+            u_0[i] = _inner_solve(Mt, mass_spec, b_0_help[i].copy())
+            u_0[i] *= 2.0 / tau
+        u_0[:] = apply_T_2_inv(u_0)
+        # b = T_2 (D_v u_0) - b_1, control.py:2016-2048
+        b = np.zeros_like(u_0)
+        b[0] = block_10[(0, 0)] @ u_0[0]
+        _bc(b[0], nodes)
+        for i in range(1, m):
+            t = block_10[(i, i - 1)] @ u_0[i - 1]
+            b[i] = block_10[(i, i)] @ u_0[i]
+            b[i] += t
+            _bc(b[i], nodes)
+        b = apply_T_2(b)
+        for i in range(m):
+            b[i] -= b_1[i]
+            _bc(b[i], nodes)
+        # forward sweep, control.py:2050-2116
+        b = apply_T_2_inv(b)
+        u_1[0] = solve(block_10[(0, 0)] + my_const * M, b[0])
+        for i in range(1, m):
+            b[i] -= block_10[(i, i - 1)] @ u_1[i - 1]
+            b[i] -= (my_const * M) @ u_1[i - 1]
+            _bc(b[i], nodes)
+            u_1[i] = solve(block_10[(i, i)] + my_const * M, b[i])
+        # control.py:2118-2133
+        u_1[:] = apply_T_2(u_1)
+        b = np.zeros_like(u_0)
+        for i in range(m):
+            b[i] = (M @ u_1[i]) * (0.5 * tau)
+            _bc(b[i], nodes)
+        # backward sweep, control.py:2135-2189
+        u_1[m - 1] = solve(block_01[(m - 1, m - 1)] + my_const * M, b[m - 1])
+        for i in range(m - 2, -1, -1):
+            b[i] -= (block_01[(i, i + 1)] + my_const * M) @ u_1[i + 1]
+            _bc(b[i], nodes)
+            u_1[i] = solve(block_01[(i, i)] + my_const * M, b[i])
+    return pc_linear
