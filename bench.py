@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Benchmark of the all-at-once KKT hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one preconditioned Krylov iteration (one KKT operator apply, one block-Schur
+preconditioner apply, one Gram-Schmidt sweep) of GMRES(10) -- the library default of the
+reference (control/control.py:3260-3266) -- on the synthetic heat-control system of
+BASELINE.json configs[1]: 2-D heat control, 256x256 P1, n_t = 64, beta = 1e-4, T = 2,
+fp64, every (i, j) time block stored with its own values ("mode G", what the reference
+stores, preconditioner.py:305-328).  W warm-up iterations, then exactly K timed ones
+(rtol = 0, so the solver runs to max_it = K), inputs resident in HBM.
+
+One JSON line on stdout (rank 0): metric/value = whole-job Krylov iterations per second;
+`roofline` = the KKT block-row SpMV kernel (kkt_spmv_rows) against the 8 TB/s HBM peak,
+timed with HIP events on the library's stream; `cpu_baseline` = the CPU oracle timed on
+this box's host cores on a bounded sample of the same workload.
+No PyTorch: the GPU process binds libkkt.so through ctypes only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def build_problem(args):
+    from control_amd.blocks import instationary_blocks
+    from control_amd.fem import unit_cube_p1, unit_square_p1
+    if args.workload == "heat2d":
+        sd = unit_square_p1(args.n)
+        mass_bounds = (0.5, 2.0)        # test_control.py:3477
+    else:
+        sd = unit_cube_p1(args.n)
+        mass_bounds = (0.5, 2.5)        # Wathen's bound for P1 tetrahedra
+    tau = args.T / (args.n_t - 1.0)
+    CN = args.scheme == "CN"
+    blocks = instationary_blocks(sd.M, sd.K, tau, args.beta, args.n_t, CN,
+                                 share=(args.mode == "S"))
+    return dict(sd=sd, tau=tau, beta=args.beta, n_t=args.n_t, CN=CN, m=blocks[4],
+                blocks=blocks[:4], nodes=sd.boundary, mass=(20,) + mass_bounds,
+                schur=(args.schur_its, args.schur_emin, args.schur_emax))
+
+
+def cpu_baseline(p, args, sample_its):
+    """The CPU oracle (port of the reference algorithm) on a bounded sample: the same
+    GMRES(10) iterations on the same system, `sample_its` of them."""
+    import common
+    from oracle import kkt_oracle as ko
+    osys = common.oracle_system(p)
+    opc = common.oracle_pc(p, p["mass"], p["schur"])
+    m, nx = p["m"], p["sd"].n_dofs
+    b = common.rng_vector(osys.N).reshape(2 * m, nx)
+    sp = {"linear_solver": "gmres", "gmres_restart": 10, "maximum_iterations": sample_its,
+          "relative_tolerance": 0.0, "absolute_tolerance": 0.0,
+          "monitor_convergence": False, "preconditioner": True}
+    u0, u1 = np.zeros((m, nx)), np.zeros((m, nx))
+    t0 = time.perf_counter()
+    res = osys.solve(u0, u1, b[:m], b[m:], solver_parameters=sp, pc_fn=opc)
+    dt = time.perf_counter() - t0
+    return {"value": res.its / dt, "unit": "Krylov iterations/s", "cores": 1,
+            "kind": "port",
+            "sample": f"{res.its} GMRES(10) iterations of the same system with the "
+                      f"NumPy/SciPy oracle, single thread, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="heat2d", choices=["heat2d", "heat3d"])
+    ap.add_argument("--n", type=int, default=256)
+    ap.add_argument("--n_t", type=int, default=64)
+    ap.add_argument("--beta", type=float, default=1.0e-4)
+    ap.add_argument("--T", type=float, default=2.0)
+    ap.add_argument("--scheme", default="BE", choices=["BE", "CN"])
+    ap.add_argument("--mode", default="G", choices=["G", "S"])
+    ap.add_argument("--schur-its", type=int, default=8)
+    ap.add_argument("--schur-emin", type=float, default=0.07)
+    ap.add_argument("--schur-emax", type=float, default=2.1)
+    ap.add_argument("--spmv-reps", type=int, default=50)
+    ap.add_argument("--cpu-its", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run "
+                             "--nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import common
+    from control_amd import _lib
+    from control_amd.dist import make_comm
+
+    p = build_problem(args)
+    comm = make_comm(rank, world, local_rank) if world > 1 else None
+    gsys = common.gpu_system(p, device=local_rank, comm=comm)
+    lib, h = gsys._lib, gsys.handle
+    gpc = common.gpu_pc(p, p["mass"], p["schur"])
+    gsys._set_pc(gpc)
+    info = gsys.info()
+    n_local = info["n_local"]
+
+    def dvec(host=None):
+        d = C.c_void_p()
+        gsys._ck(lib.kkt_vec_alloc(h, C.byref(d)))
+        if host is not None:
+            a, pa = _lib.f64(host)
+            gsys._ck(lib.kkt_vec_upload(h, d, pa))
+        return d
+
+    x = common.rng_vector(n_local, common.SEED + rank)
+    d_x, d_y = dvec(x), dvec()
+
+    # ---- roofline leg: the KKT block-row SpMV, HIP events on the library's stream
+    ms = C.c_float()
+    gsys._ck(lib.kkt_time_apply(h, d_x, d_y, 5, C.byref(ms)))          # warm-up
+    gsys._ck(lib.kkt_time_apply(h, d_x, d_y, args.spmv_reps, C.byref(ms)))
+    spmv_ms = ms.value / args.spmv_reps
+    alg_bytes = info["bytes_algorithmic"]
+    achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9
+    gsys._ck(lib.kkt_time_pc_apply(h, d_x, d_y, 2, C.byref(ms)))
+    gsys._ck(lib.kkt_time_pc_apply(h, d_x, d_y, 5, C.byref(ms)))
+    pc_ms = ms.value / 5
+
+    # ---- Krylov leg: W warm-up iterations, then exactly K timed ones
+    d_b, d_u = dvec(x), dvec()
+
+    def run(max_it):
+        gsys._ck(lib.kkt_vec_upload(h, d_u, _lib.f64(np.zeros(n_local))[1]))
+        gsys._ck(lib.kkt_set_krylov(h, 0, -1, 10, 0.0, 0.0, 1e300, max_it))
+        its, reason, nh, rn = C.c_int(), C.c_int(), C.c_int(), C.c_double()
+        gsys._ck(lib.kkt_comm_barrier(h))
+        gsys._ck(lib.kkt_sync(h))
+        t0 = time.perf_counter()
+        gsys._ck(lib.kkt_solve_device(h, d_b, d_u, C.byref(its), C.byref(reason),
+                                      C.byref(rn), None, 0, C.byref(nh)))
+        gsys._ck(lib.kkt_sync(h))
+        gsys._ck(lib.kkt_comm_barrier(h))
+        dt = C.c_double(time.perf_counter() - t0)
+        gsys._ck(lib.kkt_comm_max(h, C.byref(dt)))
+        return its.value, dt.value
+
+    if args.warmup > 0:
+        run(args.warmup)
+    its, dt = run(args.steps)
+    assert its == args.steps, (its, args.steps)
+
+    if rank != 0:
+        return
+    out = {
+        "metric": "Krylov iterations/s (preconditioned GMRES(10), all-at-once heat-control KKT)",
+        "value": its / dt, "unit": "Krylov iterations/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / its,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": (f"{'2-D' if args.workload == 'heat2d' else '3-D'} heat control, "
+                         f"{args.n}^{2 if args.workload == 'heat2d' else 3} P1, n_t={args.n_t}, "
+                         f"beta={args.beta:g}, T={args.T:g}, {args.scheme}, mode {args.mode}"),
+            "unknowns": int(2 * p["m"] * p["sd"].n_dofs),
+            "krylov": "gmres, left preconditioning, restart 10, classical Gram-Schmidt",
+            "preconditioner": (f"block Schur: mass Chebyshev {p['mass']}, "
+                               f"Schur Chebyshev {p['schur']} (its, emin, emax)"),
+            "parallelism": f"time-block rows over {world} GPU(s)",
+            "pc_apply_ms": pc_ms, "kkt_apply_ms": spmv_ms},
+        "roofline": {
+            "kernel": "kkt_spmv_rows (fused block-row SpMV of the KKT operator)",
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": spmv_ms,
+            "device_bytes_per_launch": (info["bytes_device_values"]
+                                        + info["bytes_device_index"] // max(1, info["n_patterns"])
+                                        + 16 * n_local),
+            "note": "algorithmic bytes = SURVEY 8d mode-" + args.mode +
+                    " CSR formula; index arrays are shared on the device"},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(p, args, args.cpu_its)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,531 @@
+// Hand-written HIP kernels of libkkt for gfx950 (MI355X, CDNA4): 64-wide wavefronts,
+// HBM-bound fp64 streaming.  No MFMA: the path is sparse, ~0.17 flop/byte.
+#include "kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+namespace kkt {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+// vector blocks start at multiples of nx doubles: only 8-byte alignment is guaranteed
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+
+__device__ __forceinline__ const double *resolve(const VRef &r, const Bases &B) {
+    if (r.base < 0) return nullptr;
+    if (r.base == 0) return reinterpret_cast<const double *>(r.off);
+    const double *p = r.base == 1 ? B.p[0] : r.base == 2 ? B.p[1] : r.base == 3 ? B.p[2] : B.p[3];
+    return p + r.off;
+}
+
+// ---------------------------------------------------------------- fused block-row SpMV
+//
+// Layout ("SELL-64R"): rows are cut into slices of C = 64*R consecutive rows; slice s
+// has width w_s = max row length in it and owns slots [slice_off[s], slice_off[s+1]).
+// Entry k of row (s*C + lane*R + q) sits at (slice_off[s] + k)*C + lane*R + q, so one
+// wave-instruction reads 64*R consecutive values (R=2: 16 B per lane, 1 KiB per wave --
+// the widest coalesced access) and each lane owns R consecutive rows.  Matrix values
+// are streamed once with non-temporal loads so they do not evict the index array and
+// the x windows, which are re-used across blocks, from the XCD's L2.
+//
+// One workgroup = 4 waves = 4 slices; blockIdx.y picks the RowOp (block row).  All RowOp
+// fields are wave-uniform and come in through scalar loads.
+template <int R>
+__device__ __forceinline__ void rowops_body(const RowOp *__restrict__ ops,
+                                                     const Bases bases) {
+    const RowOp &op = ops[blockIdx.y];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + wave;
+    if (s >= op.nslices) return;
+    constexpr int C = 64 * R;
+    const int off0 = op.slice_off[s];
+    const int w = op.slice_off[s + 1] - off0;
+    const size_t base = (size_t)off0 * C + (size_t)lane * R;
+    const int32_t *__restrict__ colp = op.col + base;
+
+    double acc[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) acc[q] = 0.0;
+
+    const int nterms = op.nterms;
+    for (int t = 0; t < nterms; ++t) {
+        const double *__restrict__ vp = op.t[t].vals + base;
+        const double *__restrict__ x = resolve(op.t[t].x, bases);
+#pragma unroll 4
+        for (int k = 0; k < w; ++k) {
+            if constexpr (R == 2) {
+                const i2 c = *reinterpret_cast<const i2 *>(colp + (size_t)k * C);
+                const d2 v = __builtin_nontemporal_load(
+                    reinterpret_cast<const d2 *>(vp + (size_t)k * C));
+                acc[0] = __builtin_fma(v.x, x[c.x], acc[0]);
+                acc[1] = __builtin_fma(v.y, x[c.y], acc[1]);
+            } else {
+                const int c = colp[(size_t)k * C];
+                const double v = __builtin_nontemporal_load(vp + (size_t)k * C);
+                acc[0] = __builtin_fma(v, x[c], acc[0]);
+            }
+        }
+    }
+
+    const int r0 = s * C + lane * R;
+    double *__restrict__ y = const_cast<double *>(resolve(op.y, bases));
+    double out[R];
+    if (op.mode == EPI_LIN) {
+        const double *yin = resolve(op.yin, bases);
+        const double *z = resolve(op.z, bases);
+        const double *mx = resolve(op.mx, bases);
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int r = r0 + q;
+            out[q] = 0.0;
+            if (r < op.nrows) {
+                const bool masked = op.rowmask != nullptr && op.rowmask[r] != 0;
+                if (masked) {
+                    out[q] = mx ? op.malpha * mx[r] : 0.0;
+                } else {
+                    double v = op.ca * acc[q];
+                    if (yin) v += op.cy * yin[r];
+                    if (z) v += op.cz * z[r];
+                    out[q] = v;
+                }
+            }
+        }
+    } else {
+        const double *b = resolve(op.b, bases);
+        const double *pk = resolve(op.pk, bases);
+        const double *pkm1 = resolve(op.pkm1, bases);
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int r = r0 + q;
+            out[q] = 0.0;
+            if (r < op.nrows) {
+                const bool masked = op.rowmask != nullptr && op.rowmask[r] != 0;
+                if (!masked) {
+                    // (1-w) p_{k-1} + w p_k + (scale w) D^-1 (b - A p_k): VecAXPBYPCZ order
+                    double v = pkm1 ? op.c1 * pkm1[r] : 0.0;
+                    if (pk) v += op.c2 * pk[r];
+                    v += op.c3 * (op.dinv[r] * (b[r] - acc[q]));
+                    out[q] = op.post2 * (op.post1 * v);
+                }
+            }
+        }
+    }
+    if constexpr (R == 2) {
+        if (r0 + 1 < op.nrows) {
+            d2u o;
+            o.x = out[0];
+            o.y = out[1];
+            *reinterpret_cast<d2u *>(y + r0) = o;
+        } else if (r0 < op.nrows) {
+            y[r0] = out[0];
+        }
+    } else {
+        if (r0 < op.nrows) y[r0] = out[0];
+    }
+}
+
+// Two entry points over one body so that profiles separate the KKT operator apply (the
+// roofline kernel of bench.py) from the many small block-row steps of the preconditioner.
+template <int R>
+__global__ __launch_bounds__(256) void kkt_spmv_rows(const RowOp *__restrict__ ops,
+                                                     const Bases bases) {
+    rowops_body<R>(ops, bases);
+}
+template <int R>
+__global__ __launch_bounds__(256) void pc_rows(const RowOp *__restrict__ ops,
+                                               const Bases bases) {
+    rowops_body<R>(ops, bases);
+}
+
+void launch_rowops(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, int R,
+                   const Bases &bases, int tag) {
+    if (nops <= 0 || max_slices <= 0) return;
+    dim3 grid((max_slices + 3) / 4, nops);
+    if (tag == 0) {
+        if (R == 2)
+            hipLaunchKernelGGL(kkt_spmv_rows<2>, grid, dim3(256), 0, s, d_ops, bases);
+        else
+            hipLaunchKernelGGL(kkt_spmv_rows<1>, grid, dim3(256), 0, s, d_ops, bases);
+    } else {
+        if (R == 2)
+            hipLaunchKernelGGL(pc_rows<2>, grid, dim3(256), 0, s, d_ops, bases);
+        else
+            hipLaunchKernelGGL(pc_rows<1>, grid, dim3(256), 0, s, d_ops, bases);
+    }
+}
+
+// ------------------------------------------------------------- value-array preparation
+
+static inline int grid_for(int64_t n, int per_block = 256, int cap = 256 * 8) {
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+__global__ void csr_to_sell_kernel(const double *__restrict__ csr,
+                                   const int32_t *__restrict__ map,
+                                   double *__restrict__ out, int64_t n) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t m = map[p];
+        out[p] = m >= 0 ? csr[m] : 0.0;
+    }
+}
+void launch_csr_to_sell(hipStream_t s, const double *csr_vals, const int32_t *sell2csr,
+                        double *sell_vals, int64_t n_padded) {
+    hipLaunchKernelGGL(csr_to_sell_kernel, dim3(grid_for(n_padded)), dim3(256), 0, s,
+                       csr_vals, sell2csr, sell_vals, n_padded);
+}
+
+__global__ void mask_columns_kernel(double *__restrict__ vals,
+                                    const int32_t *__restrict__ col,
+                                    const uint8_t *__restrict__ colmask, int64_t n) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        if (colmask[col[p]]) vals[p] = 0.0;
+    }
+}
+void launch_mask_columns(hipStream_t s, double *sell_vals, const int32_t *col,
+                         const uint8_t *colmask, int64_t n_padded) {
+    hipLaunchKernelGGL(mask_columns_kernel, dim3(grid_for(n_padded)), dim3(256), 0, s,
+                       sell_vals, col, colmask, n_padded);
+}
+
+__global__ void vals_axpy_kernel(double *__restrict__ out, const double *__restrict__ a,
+                                 double c, const double *__restrict__ b, int64_t n) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        out[p] = __dadd_rn(a ? a[p] : 0.0, __dmul_rn(c, b[p]));
+    }
+}
+void launch_vals_axpy(hipStream_t s, double *out, const double *a, double c,
+                      const double *b, int64_t n_padded) {
+    hipLaunchKernelGGL(vals_axpy_kernel, dim3(grid_for(n_padded)), dim3(256), 0, s, out, a,
+                       c, b, n_padded);
+}
+
+template <int R>
+__global__ void extract_dinv_kernel(const int32_t *__restrict__ col,
+                                    const int32_t *__restrict__ slice_off,
+                                    const double *__restrict__ vals,
+                                    const uint8_t *__restrict__ rowmask,
+                                    double *__restrict__ dinv, int nrows, int nslices) {
+    constexpr int C = 64 * R;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const int s = r / C;
+    const int within = r - s * C;
+    const int off0 = slice_off[s];
+    const int w = slice_off[s + 1] - off0;
+    double d = 1.0;
+    for (int k = 0; k < w; ++k) {
+        const size_t p = ((size_t)off0 + k) * C + within;
+        if (col[p] == r) {
+            d = vals[p];
+            break;
+        }
+    }
+    const bool masked = rowmask != nullptr && rowmask[r] != 0;
+    dinv[r] = masked ? 1.0 : 1.0 / d;
+}
+void launch_extract_dinv(hipStream_t s, const int32_t *col, const int32_t *slice_off,
+                         const double *vals, const uint8_t *rowmask, double *dinv,
+                         int nrows, int nslices, int R) {
+    dim3 grid((nrows + 255) / 256);
+    if (R == 2)
+        hipLaunchKernelGGL(extract_dinv_kernel<2>, grid, dim3(256), 0, s, col, slice_off,
+                           vals, rowmask, dinv, nrows, nslices);
+    else
+        hipLaunchKernelGGL(extract_dinv_kernel<1>, grid, dim3(256), 0, s, col, slice_off,
+                           vals, rowmask, dinv, nrows, nslices);
+}
+
+// ----------------------------------------------------------------------- vector kernels
+
+__global__ void copy_kernel(double *__restrict__ y, const double *__restrict__ x,
+                            int64_t n) {
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n2; p += stride)
+        reinterpret_cast<d2 *>(y)[p] = reinterpret_cast<const d2 *>(x)[p];
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = x[n - 1];
+}
+void launch_copy(hipStream_t s, double *y, const double *x, int64_t n) {
+    if (n <= 0 || y == x) return;
+    hipLaunchKernelGGL(copy_kernel, dim3(grid_for(n >> 1)), dim3(256), 0, s, y, x, n);
+}
+
+__global__ void fill_kernel(double *__restrict__ y, double v, int64_t n) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n;
+         p += (int64_t)gridDim.x * blockDim.x)
+        y[p] = v;
+}
+void launch_fill(hipStream_t s, double *y, double v, int64_t n) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, v, n);
+}
+
+__global__ void axpby_kernel(double *__restrict__ y, double a, const double *__restrict__ x,
+                             double b, int64_t n) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n;
+         p += (int64_t)gridDim.x * blockDim.x)
+        y[p] = a * x[p] + b * y[p];
+}
+void launch_axpby(hipStream_t s, double *y, double a, const double *x, double b,
+                  int64_t n) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, a, x, b, n);
+}
+
+__global__ void mask_blocks_kernel(double *__restrict__ y, const double *__restrict__ x,
+                                   const double *__restrict__ mx,
+                                   const MaskJob *__restrict__ jobs, int64_t nx) {
+    const MaskJob job = jobs[blockIdx.y];
+    const int64_t off = (int64_t)blockIdx.y * nx;
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < nx;
+         r += (int64_t)gridDim.x * blockDim.x) {
+        const bool masked = job.mask != nullptr && job.mask[r] != 0;
+        double v;
+        if (masked)
+            v = mx ? job.alpha * mx[off + r] : 0.0;
+        else
+            v = x[off + r];
+        y[off + r] = v;
+    }
+}
+void launch_mask_blocks(hipStream_t s, double *y, const double *x, const double *mx,
+                        const MaskJob *d_jobs, int nblocks, int64_t nx) {
+    if (nblocks <= 0 || nx <= 0) return;
+    dim3 grid(grid_for(nx, 256, 64), nblocks);
+    hipLaunchKernelGGL(mask_blocks_kernel, grid, dim3(256), 0, s, y, x, mx, d_jobs, nx);
+}
+
+__global__ void time_transform_kernel(double *__restrict__ y, const double *__restrict__ x,
+                                      int kind, int n, int64_t nx,
+                                      const double *__restrict__ lo_halo,
+                                      const double *__restrict__ hi_halo) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < nx;
+         r += (int64_t)gridDim.x * blockDim.x) {
+        if (kind == 1) {          // T_1: new_i = old_i + old_{i+1}
+            double cur = x[r];
+            for (int i = 0; i < n; ++i) {
+                double nxt = 0.0;
+                if (i + 1 < n)
+                    nxt = x[(int64_t)(i + 1) * nx + r];
+                else if (hi_halo)
+                    nxt = hi_halo[r];
+                const bool has = (i + 1 < n) || hi_halo;
+                y[(int64_t)i * nx + r] = has ? cur + nxt : cur;
+                cur = nxt;
+            }
+        } else if (kind == 2) {   // T_2: new_i = old_i + old_{i-1}
+            double prev = lo_halo ? lo_halo[r] : 0.0;
+            bool has = lo_halo != nullptr;
+            for (int i = 0; i < n; ++i) {
+                const double cur = x[(int64_t)i * nx + r];
+                y[(int64_t)i * nx + r] = has ? cur + prev : cur;
+                prev = cur;
+                has = true;
+            }
+        } else if (kind == 3) {   // T_1^{-1}: for i = n-2..0: x_i -= x_{i+1} (updated)
+            double nxt = hi_halo ? hi_halo[r] : 0.0;
+            bool has = hi_halo != nullptr;
+            for (int i = n - 1; i >= 0; --i) {
+                double cur = x[(int64_t)i * nx + r];
+                if (has) cur -= nxt;
+                y[(int64_t)i * nx + r] = cur;
+                nxt = cur;
+                has = true;
+            }
+        } else {                  // T_2^{-1}: for i = 1..n-1: x_i -= x_{i-1} (updated)
+            double prev = lo_halo ? lo_halo[r] : 0.0;
+            bool has = lo_halo != nullptr;
+            for (int i = 0; i < n; ++i) {
+                double cur = x[(int64_t)i * nx + r];
+                if (has) cur -= prev;
+                y[(int64_t)i * nx + r] = cur;
+                prev = cur;
+                has = true;
+            }
+        }
+    }
+}
+void launch_time_transform(hipStream_t s, double *y, const double *x, int kind, int n,
+                           int64_t nx, const double *lo_halo, const double *hi_halo) {
+    if (n <= 0 || nx <= 0) return;
+    hipLaunchKernelGGL(time_transform_kernel, dim3(grid_for(nx)), dim3(256), 0, s, y, x,
+                       kind, n, nx, lo_halo, hi_halo);
+}
+
+// one workgroup per block: fixed-order sum (deterministic)
+__global__ void block_sums_kernel(const double *__restrict__ x, double *__restrict__ sums,
+                                  int64_t nx) {
+    __shared__ double sh[256];
+    const double *xb = x + (int64_t)blockIdx.x * nx;
+    double a = 0.0;
+    for (int64_t r = threadIdx.x; r < nx; r += 256) a += xb[r];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[blockIdx.x] = sh[0];
+}
+void launch_block_sums(hipStream_t s, const double *x, double *sums, int n, int64_t nx,
+                       double *) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(block_sums_kernel, dim3(n), dim3(256), 0, s, x, sums, nx);
+}
+__global__ void block_shift_kernel(double *__restrict__ y, const double *__restrict__ sums,
+                                   double coef, int64_t nx) {
+    const double sh = coef * sums[blockIdx.y];
+    double *yb = y + (int64_t)blockIdx.y * nx;
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < nx;
+         r += (int64_t)gridDim.x * blockDim.x)
+        yb[r] += sh;
+}
+void launch_block_shift(hipStream_t s, double *y, const double *sums, double coef, int n,
+                        int64_t nx) {
+    if (n <= 0) return;
+    dim3 grid(grid_for(nx, 256, 64), n);
+    hipLaunchKernelGGL(block_shift_kernel, grid, dim3(256), 0, s, y, sums, coef, nx);
+}
+
+// -------------------------------------------------------------------------- reductions
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// stage 1: REDUCE_BLOCKS workgroups, each a fixed contiguous chunk; lane partials are
+// combined by wavefront shuffles, then the 4 wave results in LDS, in a fixed order.
+template <int NV>
+__global__ __launch_bounds__(256) void mdot_stage1(const double *__restrict__ w, VecList V,
+                                                   int64_t n, double *__restrict__ part) {
+    __shared__ double sh[4][MDOT_MAX];
+    const int64_t chunk = ((n + REDUCE_BLOCKS - 1) / REDUCE_BLOCKS + 1) & ~(int64_t)1;
+    const int64_t lo = (int64_t)blockIdx.x * chunk;
+    int64_t hi = lo + chunk;
+    if (hi > n) hi = n;
+    double acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+    // chunk is even and lo is even -> 16-byte aligned double2 accesses
+    int64_t p = lo + 2 * (int64_t)threadIdx.x;
+    for (; p + 1 < hi; p += 512) {
+        const d2 wv = *reinterpret_cast<const d2 *>(w + p);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const d2 vv = *reinterpret_cast<const d2 *>(V.v[i] + p);
+            acc[i] = __builtin_fma(wv.x, vv.x, acc[i]);
+            acc[i] = __builtin_fma(wv.y, vv.y, acc[i]);
+        }
+    }
+    if (p < hi) {
+        const double wv = w[p];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc[i] = __builtin_fma(wv, V.v[i][p], acc[i]);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const double t = wave_sum(acc[i]);
+        if (lane == 0) sh[wave][i] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        const int i = threadIdx.x;
+        part[(int64_t)blockIdx.x * MDOT_MAX + i] = ((sh[0][i] + sh[1][i]) + sh[2][i]) + sh[3][i];
+    }
+}
+
+// stage 2: one workgroup per vector sums the REDUCE_BLOCKS partials in a fixed tree
+__global__ __launch_bounds__(256) void mdot_stage2(const double *__restrict__ part,
+                                                   double *__restrict__ out) {
+    __shared__ double sh[256];
+    const int i = blockIdx.x;
+    double a = 0.0;
+    for (int b = threadIdx.x; b < REDUCE_BLOCKS; b += 256) a += part[(int64_t)b * MDOT_MAX + i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[i] = sh[0];
+}
+
+void launch_mdot(hipStream_t s, const double *w, VecList V, int nv, int64_t n,
+                 double *scratch, double *out) {
+    if (nv <= 0) return;
+    dim3 g(REDUCE_BLOCKS), b(256);
+    switch (nv) {
+        case 1: hipLaunchKernelGGL(mdot_stage1<1>, g, b, 0, s, w, V, n, scratch); break;
+        case 2: hipLaunchKernelGGL(mdot_stage1<2>, g, b, 0, s, w, V, n, scratch); break;
+        case 3: hipLaunchKernelGGL(mdot_stage1<3>, g, b, 0, s, w, V, n, scratch); break;
+        case 4: hipLaunchKernelGGL(mdot_stage1<4>, g, b, 0, s, w, V, n, scratch); break;
+        case 5: hipLaunchKernelGGL(mdot_stage1<5>, g, b, 0, s, w, V, n, scratch); break;
+        case 6: hipLaunchKernelGGL(mdot_stage1<6>, g, b, 0, s, w, V, n, scratch); break;
+        case 7: hipLaunchKernelGGL(mdot_stage1<7>, g, b, 0, s, w, V, n, scratch); break;
+        default: hipLaunchKernelGGL(mdot_stage1<8>, g, b, 0, s, w, V, n, scratch); break;
+    }
+    hipLaunchKernelGGL(mdot_stage2, dim3(nv), b, 0, s, scratch, out);
+}
+
+__global__ void norm2_finish_kernel(const double *dot, double *out) {
+    out[0] = sqrt(dot[0]);
+}
+void launch_norm2_finish(hipStream_t s, const double *dot, double *out) {
+    hipLaunchKernelGGL(norm2_finish_kernel, dim3(1), dim3(1), 0, s, dot, out);
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void maxpy_kernel(double *__restrict__ w, VecList V,
+                                                    const double *__restrict__ coef,
+                                                    double sign, int64_t n) {
+    double c[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) c[i] = coef[i];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += stride) {
+        double a = 0.0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) a = __builtin_fma(c[i], V.v[i][p], a);
+        w[p] = __builtin_fma(sign, a, w[p]);
+    }
+}
+void launch_maxpy(hipStream_t s, double *w, VecList V, const double *coef, double sign,
+                  int nv, int64_t n) {
+    if (nv <= 0 || n <= 0) return;
+    dim3 g(grid_for(n)), b(256);
+    switch (nv) {
+        case 1: hipLaunchKernelGGL(maxpy_kernel<1>, g, b, 0, s, w, V, coef, sign, n); break;
+        case 2: hipLaunchKernelGGL(maxpy_kernel<2>, g, b, 0, s, w, V, coef, sign, n); break;
+        case 3: hipLaunchKernelGGL(maxpy_kernel<3>, g, b, 0, s, w, V, coef, sign, n); break;
+        case 4: hipLaunchKernelGGL(maxpy_kernel<4>, g, b, 0, s, w, V, coef, sign, n); break;
+        case 5: hipLaunchKernelGGL(maxpy_kernel<5>, g, b, 0, s, w, V, coef, sign, n); break;
+        case 6: hipLaunchKernelGGL(maxpy_kernel<6>, g, b, 0, s, w, V, coef, sign, n); break;
+        case 7: hipLaunchKernelGGL(maxpy_kernel<7>, g, b, 0, s, w, V, coef, sign, n); break;
+        default: hipLaunchKernelGGL(maxpy_kernel<8>, g, b, 0, s, w, V, coef, sign, n); break;
+    }
+}
+
+__global__ void scale_inv_kernel(double *__restrict__ y, const double *__restrict__ x,
+                                 const double *__restrict__ norm, int64_t n) {
+    const double inv = 1.0 / norm[0];
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n;
+         p += (int64_t)gridDim.x * blockDim.x)
+        y[p] = x[p] * inv;
+}
+void launch_scale_inv(hipStream_t s, double *y, const double *x, const double *norm,
+                      int64_t n) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(scale_inv_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, x, norm, n);
+}
+
+}  // namespace kkt

@@ -1,0 +1,103 @@
+// Device-kernel interface of libkkt (host-callable launchers).  gfx950 only.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace kkt {
+
+constexpr int MAX_TERMS = 8;      // blocks summed into one block row by one launch
+constexpr int MDOT_MAX = 8;       // vectors per fused multi-dot / multi-axpy pass
+constexpr int REDUCE_BLOCKS = 1024;  // fixed partial count -> deterministic reductions
+
+// Reference to a vector operand.  base < 0: null; base == 0: `off` holds an absolute
+// device pointer; base >= 1: element offset `off` from Bases::p[base - 1], which the
+// caller supplies per launch (so one RowOp array serves any input/output vector).
+struct VRef {
+    int64_t off;
+    int32_t base;
+    int32_t pad_;
+};
+struct Bases { const double *p[4]; };
+
+struct SpmvTerm {
+    const double *vals;   // padded SELL values (layout of the RowOp's pattern)
+    VRef x;               // the column block's vector (length ncols)
+};
+
+enum EpiMode : int32_t { EPI_LIN = 0, EPI_CHEB = 1 };
+
+// One block-row operation.  Arrays of RowOp live in device memory; one launch executes
+// many of them (blockIdx.y selects the RowOp).  acc = sum_t A_t x_t is accumulated
+// term-major with one fused-multiply-add chain per row, in CSR order within a term --
+// the order of the reference's sequence of MatMultAdd calls (preconditioner.py:406-432).
+struct RowOp {
+    const int32_t *col;        // SELL column indices of the shared pattern
+    const int32_t *slice_off;  // nslices + 1 offsets, in slots
+    int32_t nrows, nslices, nterms, mode;
+    SpmvTerm t[MAX_TERMS];
+    VRef y;
+    // EPI_LIN:  y = ca*acc + cy*yin + cz*z;  masked rows: y = malpha * mx[r] (0 if !mx)
+    double ca, cy, cz;
+    VRef yin, z;
+    const uint8_t *rowmask;
+    VRef mx;
+    double malpha;
+    // EPI_CHEB: y = post2*(post1*(c1*pkm1 + c2*pk + c3*dinv*(b - acc))); masked rows use
+    //           the exact result of the bc-assembled matrix on a bc-clean rhs: 0
+    VRef b, pkm1, pk;
+    const double *dinv;
+    double c1, c2, c3, post1, post2;
+};
+
+void launch_rowops(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, int R,
+                   const Bases &bases, int tag);
+
+// ---- value-array preparation
+void launch_csr_to_sell(hipStream_t s, const double *csr_vals, const int32_t *sell2csr,
+                        double *sell_vals, int64_t n_padded);
+void launch_mask_columns(hipStream_t s, double *sell_vals, const int32_t *col,
+                         const uint8_t *colmask, int64_t n_padded);
+// out = a + c * b (no fma contraction: matches "assemble(block + c * M)")
+void launch_vals_axpy(hipStream_t s, double *out, const double *a, double c,
+                      const double *b, int64_t n_padded);
+// dinv[r] = rowmask[r] ? 1 : 1 / diag(A)[r]
+void launch_extract_dinv(hipStream_t s, const int32_t *col, const int32_t *slice_off,
+                         const double *vals, const uint8_t *rowmask, double *dinv,
+                         int nrows, int nslices, int R);
+
+// ---- vector kernels (all lengths in doubles)
+void launch_copy(hipStream_t s, double *y, const double *x, int64_t n);
+void launch_fill(hipStream_t s, double *y, double v, int64_t n);
+// y = a*x + b*y
+void launch_axpby(hipStream_t s, double *y, double a, const double *x, double b, int64_t n);
+// y[k*nx + r] = mask_k[r] ? (mx ? alpha_k * mx[k*nx + r] : 0) : x[k*nx + r]
+struct MaskJob { const uint8_t *mask; double alpha; };
+void launch_mask_blocks(hipStream_t s, double *y, const double *x, const double *mx,
+                        const MaskJob *d_jobs, int nblocks, int64_t nx);
+// CN time transforms over `n` consecutive blocks of length nx (block stride nx):
+// kind 1: T_1 (new_i = old_i + old_{i+1}); 2: T_2; 3: T_1^{-1}; 4: T_2^{-1}
+// (preconditioner.py:33-60, control.py:63-96).  `lo_halo`/`hi_halo` (may be null) stand
+// for the block before the first / after the last one on a time-sharded handle.
+void launch_time_transform(hipStream_t s, double *y, const double *x, int kind, int n,
+                           int64_t nx, const double *lo_halo, const double *hi_halo);
+// y_k += shift_k for `n` blocks where shift_k = coef * sums[k] (ConstantNullspace)
+void launch_block_shift(hipStream_t s, double *y, const double *sums, double coef, int n,
+                        int64_t nx);
+void launch_block_sums(hipStream_t s, const double *x, double *sums, int n, int64_t nx,
+                       double *scratch);
+
+// ---- reductions (two fixed stages, no atomics: bitwise reproducible)
+struct VecList { const double *v[MDOT_MAX]; };
+// out[i] = <w, V_i>, i < nv <= MDOT_MAX.  scratch: REDUCE_BLOCKS * MDOT_MAX doubles.
+void launch_mdot(hipStream_t s, const double *w, VecList V, int nv, int64_t n,
+                 double *scratch, double *out);
+// out[0] = sqrt(<w, w> + extra) where extra = (add ? *add : 0)
+void launch_norm2_finish(hipStream_t s, const double *dot, double *out);
+// w += sign * sum_i coef[i] * V_i   (coef in device memory)
+void launch_maxpy(hipStream_t s, double *w, VecList V, const double *coef, double sign,
+                  int nv, int64_t n);
+// y = x * (1 / *norm)
+void launch_scale_inv(hipStream_t s, double *y, const double *x, const double *norm,
+                      int64_t n);
+
+}  // namespace kkt

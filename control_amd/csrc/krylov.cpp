@@ -1,0 +1,334 @@
+// Preconditioner wrapper and Krylov loop on device-resident vectors.
+//   System::pc_apply  <- Preconditioner.apply      (reference preconditioner.py:562-656)
+//   System::solve     <- MultiBlockSystem.solve    (preconditioner.py:658-766) with the PETSc
+//                        KSPSolve_GMRES / KSPSolve_FGMRES loop it calls at :758-759 restated:
+//                        classical Gram-Schmidt without refinement, Givens rotations,
+//                        KSPConvergedDefault against the norm of the (preconditioned) rhs
+//                        because the initial guess is flagged non-zero (:743).
+// All vector work is HIP kernels on the system's stream; the host sees one small
+// device-to-host copy per iteration (the new Hessenberg column and the norm).
+#include <chrono>
+#include <cmath>
+#include <vector>
+
+#include "comm.hpp"
+#include "pc.hpp"
+#include "system.hpp"
+
+namespace kkt {
+
+void System::mdot(const double *w, const double *const *V, int nv, double *d_out) {
+    for (int g = 0; g < nv; g += MDOT_MAX) {
+        const int m = std::min(MDOT_MAX, nv - g);
+        VecList L{};
+        for (int i = 0; i < m; ++i) L.v[i] = V[g + i];
+        launch_mdot(stream, w, L, m, n_local, d_red_scratch, d_out + g);
+    }
+    if (sharded) comm->allreduce_sum(d_out, nv, stream);
+}
+
+void System::norm2(const double *w, double *d_out) {
+    const double *V[1] = {w};
+    mdot(w, V, 1, d_out + 1);
+    launch_norm2_finish(stream, d_out + 1, d_out);
+}
+
+void System::ensure_workspace(int restart, bool flexible) {
+    if (d_V && ws_restart >= restart && (ws_flexible || !flexible)) return;
+    auto F = [](double *&p) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    };
+    F(d_V);
+    F(d_Z);
+    d_V = dev_alloc<double>((size_t)(restart + 1) * vec_stride);
+    HIPCHK(hipMemsetAsync(d_V, 0, (size_t)(restart + 1) * vec_stride * 8, stream));
+    if (flexible) {
+        d_Z = dev_alloc<double>((size_t)restart * vec_stride);
+        HIPCHK(hipMemsetAsync(d_Z, 0, (size_t)restart * vec_stride * 8, stream));
+    }
+    if (!d_t1) d_t1 = new_vec();
+    if (!d_t2) d_t2 = new_vec();
+    if (!d_rhs) d_rhs = new_vec();
+    if (!d_red_scratch) d_red_scratch = dev_alloc<double>((size_t)REDUCE_BLOCKS * MDOT_MAX);
+    F(d_hcol);
+    F(d_coef);
+    d_hcol = dev_alloc<double>(restart + 16);
+    d_coef = dev_alloc<double>(restart + 16);
+    if (h_pinned) (void)hipHostFree(h_pinned);
+    HIPCHK(hipHostMalloc((void **)&h_pinned, (restart + 16) * sizeof(double), 0));
+    ws_restart = restart;
+    ws_flexible = flexible;
+}
+
+static void per_var(const System &S, double *y, const double *x, const double *mx,
+                    const MaskJob *jobs) {
+    if (S.nx0 == S.nx1) {
+        launch_mask_blocks(S.stream, y, x, mx, jobs, S.n0_loc + S.n1_loc, S.nx0);
+    } else {
+        const int64_t o = (int64_t)S.n0_loc * S.nx0;
+        launch_mask_blocks(S.stream, y, x, mx, jobs, S.n0_loc, S.nx0);
+        launch_mask_blocks(S.stream, y + o, x + o, mx ? mx + o : nullptr, jobs + S.n0_loc,
+                           S.n1_loc, S.nx1);
+    }
+}
+
+template <class F>
+static void for_const_blocks(System &S, F f) {
+    for (int var = 0; var < 2; ++var) {
+        const int nloc = var == 0 ? S.n0_loc : S.n1_loc;
+        const int64_t nxv = var == 0 ? S.nx0 : S.nx1;
+        for (int il = 0; il < nloc; ++il) {
+            const int g = var == 0 ? S.global_row(0, il) : S.n0 + S.global_row(1, il);
+            if (S.nullspaces[g].kind == 2) f(S.local_offset(var, il), nxv, S.nullspaces[g]);
+        }
+    }
+}
+
+void System::ns_project(double *y, const double *x) {
+    per_var(*this, y, x, nullptr, d_mask_jobs);
+    if (any_const_ns)
+        for_const_blocks(*this, [&](int64_t off, int64_t nxv, const NullspaceSpec &) {
+            launch_block_sums(stream, y + off, d_sums, 1, nxv, nullptr);
+            launch_block_shift(stream, y + off, d_sums, -1.0 / (double)nxv, 1, nxv);
+        });
+}
+
+void System::ns_pc_post(double *y, const double *u, const double *b) {
+    per_var(*this, y, u, b, d_mask_jobs_one);
+    if (any_const_ns)
+        for_const_blocks(*this, [&](int64_t off, int64_t nxv, const NullspaceSpec &) {
+            launch_block_sums(stream, y + off, d_sums, 1, nxv, nullptr);
+            launch_block_shift(stream, y + off, d_sums, -1.0 / (double)nxv, 1, nxv);
+            launch_block_sums(stream, b + off, d_sums, 1, nxv, nullptr);
+            launch_block_shift(stream, y + off, d_sums, 1.0 / (double)nxv, 1, nxv);
+        });
+}
+
+// y = P pc_fn(P x) + (I - P) x   (preconditioner.py:562-656)
+void System::pc_apply(const double *d_x, double *d_y) {
+    if (!finalized) fail(KKT_ERR_STATE, "system not finalized");
+    info.last_pc_applies++;
+    double *in, *out;
+    if (pc) {
+        in = pc->in();
+        out = pc->out();
+    } else {
+        if (!d_pc_in) d_pc_in = new_vec();
+        if (!d_pc_out) d_pc_out = new_vec();
+        in = d_pc_in;
+        out = d_pc_out;
+    }
+    ns_project(in, d_x);   // b_c = pc_pre_mult_corrected(b)
+    if (pc) {
+        pc->run();
+    } else if (pc_cb) {
+        std::vector<double> hb(n_local), hu(n_local, 0.0);
+        HIPCHK(hipMemcpyAsync(hb.data(), in, n_local * 8, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        const int64_t o = (int64_t)n0_loc * nx0;
+        if (pc_cb(pc_cb_user, hb.data(), hb.data() + o, hu.data(), hu.data() + o) != 0) {
+            pc_cb_failed = true;   // the reference's _error_flag (preconditioner.py:64-72)
+        }
+        HIPCHK(hipMemcpyAsync(out, hu.data(), n_local * 8, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+    } else {
+        launch_copy(stream, out, in, n_local);   // default pc_fn: u = b (:342-345)
+    }
+    ns_pc_post(d_y, out, d_x);
+}
+
+namespace {
+
+struct Conv {   // KSPConvergedDefault
+    double atol, divtol, rnorm0, ttol;
+    Conv(double rtol, double atol_, double divtol_, double rnorm0_)
+        : atol(atol_), divtol(divtol_), rnorm0(rnorm0_), ttol(std::max(rtol * rnorm0_, atol_)) {}
+    int operator()(double rn) const {
+        if (!std::isfinite(rn)) return KKT_DIVERGED_NANORINF;
+        if (rn <= ttol) return rn < atol ? KKT_CONVERGED_ATOL : KKT_CONVERGED_RTOL;
+        if (rn >= divtol * rnorm0) return KKT_DIVERGED_DTOL;
+        return 0;
+    }
+};
+
+}  // namespace
+
+void System::solve(const double *d_b, double *d_u, int *its_out, int *reason_out,
+                   double *rnorm_out, double *hist, int hist_cap, int *hist_len) {
+    if (!finalized) fail(KKT_ERR_STATE, "system not finalized");
+    const bool flexible = ksp.type == KKT_KSP_FGMRES;
+    bool right = flexible;
+    if (!flexible && ksp.pc_side == KKT_PC_RIGHT) right = true;
+    if (flexible && ksp.pc_side == KKT_PC_LEFT)
+        fail(KKT_ERR_ARG, "fgmres supports right preconditioning only");
+    const int m = ksp.restart;
+    ensure_workspace(m, flexible);
+    pc_cb_failed = false;
+    info.last_pc_applies = 0;
+    info.last_op_applies = 0;
+    auto Vp = [&](int k) { return d_V + (size_t)k * vec_stride; };
+    auto Zp = [&](int k) { return d_Z + (size_t)k * vec_stride; };
+    auto read_scalars = [&](const double *d_src, int n) {
+        HIPCHK(hipMemcpyAsync(h_pinned, d_src, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+    };
+    int nh = 0;
+    auto log = [&](double rn) {
+        if (hist && nh < hist_cap) hist[nh] = rn;
+        ++nh;
+    };
+
+    // corrected initial guess and right-hand side (preconditioner.py:658-704)
+    ns_project(d_u, d_u);
+    ns_project(d_rhs, d_b);
+    const double *b = d_rhs;
+
+    sync();
+    const auto t_begin = std::chrono::steady_clock::now();
+
+    // rnorm0 = norm of the (preconditioned) right-hand side
+    double rnorm0;
+    if (right) {
+        norm2(b, d_hcol);
+    } else {
+        pc_apply(b, d_t2);
+        norm2(d_t2, d_hcol);
+    }
+    read_scalars(d_hcol, 1);
+    rnorm0 = h_pinned[0];
+    const Conv conv(ksp.rtol, ksp.atol, ksp.divtol, rnorm0);
+    const double haptol = 1.0e-30;
+
+    std::vector<double> H((size_t)(m + 1) * m, 0.0), cc(m, 0.0), ss(m, 0.0), grs(m + 1, 0.0);
+    auto Hm = [&](int r, int c) -> double & { return H[(size_t)c * (m + 1) + r]; };
+    int its = 0, reason = 0;
+    double rn = 0.0;
+    while (true) {
+        // KSPInitialResidual
+        apply(d_u, d_t1);
+        if (right) {
+            launch_copy(stream, Vp(0), b, n_local);
+            launch_axpby(stream, Vp(0), -1.0, d_t1, 1.0, n_local);
+        } else {
+            launch_copy(stream, d_t2, b, n_local);
+            launch_axpby(stream, d_t2, -1.0, d_t1, 1.0, n_local);
+            pc_apply(d_t2, Vp(0));
+        }
+        norm2(Vp(0), d_hcol);
+        read_scalars(d_hcol, 1);
+        rn = h_pinned[0];
+        log(rn);
+        if (rn == 0.0) {
+            reason = KKT_CONVERGED_ATOL;
+            break;
+        }
+        launch_scale_inv(stream, Vp(0), Vp(0), d_hcol, n_local);
+        std::fill(grs.begin(), grs.end(), 0.0);
+        grs[0] = rn;
+        reason = conv(rn);
+        int it = 0;
+        std::fill(H.begin(), H.end(), 0.0);
+        while (!reason && it < m && its < ksp.max_it) {
+            if (it) log(rn);
+            double *w = Vp(it + 1);
+            if (right) {
+                double *z = flexible ? Zp(it) : d_t2;
+                pc_apply(Vp(it), z);
+                apply(z, w);
+            } else {
+                apply(Vp(it), d_t1);
+                pc_apply(d_t1, w);
+            }
+            // classical Gram-Schmidt: h = V^T w; w -= V h; tt = ||w||
+            std::vector<const double *> Vl(it + 1);
+            for (int k = 0; k <= it; ++k) Vl[k] = Vp(k);
+            mdot(w, Vl.data(), it + 1, d_hcol);
+            for (int g = 0; g <= it; g += MDOT_MAX) {
+                const int mm = std::min(MDOT_MAX, it + 1 - g);
+                VecList L{};
+                for (int i = 0; i < mm; ++i) L.v[i] = Vl[g + i];
+                launch_maxpy(stream, w, L, d_hcol + g, -1.0, mm, n_local);
+            }
+            double *d_tt = d_hcol + (it + 1);   // [tt, scratch]
+            norm2(w, d_tt);
+            read_scalars(d_hcol, it + 2);
+            for (int k = 0; k <= it; ++k) Hm(k, it) = h_pinned[k];
+            const double tt = h_pinned[it + 1];
+            const double hapbnd = std::min(std::fabs(tt / grs[it]), haptol);
+            const bool hapend = tt < hapbnd;
+            if (!hapend) launch_scale_inv(stream, w, w, d_tt, n_local);
+            Hm(it + 1, it) = tt;
+            // KSPGMRESUpdateHessenberg
+            for (int j = 0; j < it; ++j) {
+                const double t = Hm(j, it);
+                Hm(j, it) = cc[j] * t + ss[j] * Hm(j + 1, it);
+                Hm(j + 1, it) = cc[j] * Hm(j + 1, it) - ss[j] * t;
+            }
+            if (!hapend) {
+                const double t = std::sqrt(Hm(it, it) * Hm(it, it) + Hm(it + 1, it) * Hm(it + 1, it));
+                if (t == 0.0) {
+                    reason = KKT_DIVERGED_BREAKDOWN;
+                    break;
+                }
+                cc[it] = Hm(it, it) / t;
+                ss[it] = Hm(it + 1, it) / t;
+                grs[it + 1] = -(ss[it] * grs[it]);
+                grs[it] = cc[it] * grs[it];
+                Hm(it, it) = cc[it] * Hm(it, it) + ss[it] * Hm(it + 1, it);
+                rn = std::fabs(grs[it + 1]);
+            } else {
+                rn = 0.0;
+            }
+            ++it;
+            ++its;
+            reason = conv(rn);
+            if (hapend && !reason) reason = KKT_DIVERGED_BREAKDOWN;
+        }
+        if (it && (reason || its >= ksp.max_it)) log(rn);
+        // KSPGMRESBuildSoln
+        if (it > 0) {
+            std::vector<double> y(it, 0.0);
+            for (int k = it - 1; k >= 0; --k) {
+                double s = grs[k];
+                for (int j = k + 1; j < it; ++j) s -= Hm(k, j) * y[j];
+                y[k] = s / Hm(k, k);
+            }
+            HIPCHK(hipMemcpyAsync(d_coef, y.data(), it * sizeof(double), hipMemcpyHostToDevice,
+                                  stream));
+            HIPCHK(hipStreamSynchronize(stream));   // y is a stack-lifetime host buffer
+            double *acc = d_u;
+            if (right && !flexible) {
+                launch_fill(stream, d_t1, 0.0, n_local);
+                acc = d_t1;
+            }
+            for (int g = 0; g < it; g += MDOT_MAX) {
+                const int mm = std::min(MDOT_MAX, it - g);
+                VecList L{};
+                for (int i = 0; i < mm; ++i) L.v[i] = flexible ? Zp(g + i) : Vp(g + i);
+                launch_maxpy(stream, acc, L, d_coef + g, 1.0, mm, n_local);
+            }
+            if (right && !flexible) {
+                pc_apply(d_t1, d_t2);
+                launch_axpby(stream, d_u, 1.0, d_t2, 1.0, n_local);
+            }
+        }
+        if (reason) break;
+        if (its >= ksp.max_it) {
+            reason = KKT_DIVERGED_ITS;
+            break;
+        }
+    }
+    // corrected solution (preconditioner.py:761-766)
+    ns_project(d_u, d_u);
+    sync();
+    info.last_solve_ms =
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    if (its_out) *its_out = its;
+    if (reason_out) *reason_out = reason;
+    if (rnorm_out) *rnorm_out = rn;
+    if (hist_len) *hist_len = nh;
+    if (pc_cb_failed) fail(KKT_ERR_CALLBACK, "Error encountered in preconditioner callback");
+}
+
+}  // namespace kkt

@@ -1,0 +1,460 @@
+#include "pc.hpp"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace kkt {
+
+static VRef vabs(const double *p) {
+    return p ? VRef{(int64_t)(uintptr_t)p, 0, 0} : VRef{0, -1, 0};
+}
+
+SchurPC::SchurPC(System &S, const kkt_pc_desc &d) : S_(S), d_(d) {
+    if (!S.finalized) fail(KKT_ERR_STATE, "kkt_set_pc_schur needs a finalized system");
+    if (d.kind < KKT_PC_STATIONARY || d.kind > KKT_PC_INSTATIONARY_CN)
+        fail(KKT_ERR_ARG, "unknown preconditioner kind");
+    if (!d.m_indptr || !d.m_indices || !d.m_values) fail(KKT_ERR_ARG, "mass matrix missing");
+    if (S.nx0 != S.nx1 || d.nx != S.nx0)
+        fail(KKT_ERR_ARG, "built-in preconditioner needs equal spatial spaces of size nx");
+    if (S.sharded) fail(KKT_ERR_STATE, "built-in preconditioner on a time-sharded system: TODO");
+    nx_ = d.nx;
+    if (d.kind == KKT_PC_STATIONARY)
+        n_ = 1;
+    else
+        n_ = d.kind == KKT_PC_INSTATIONARY_BE ? d.n_t : d.n_t - 1;
+    if (n_ != S.n0 || n_ != S.n1 || n_ < 1)
+        fail(KKT_ERR_ARG, "n_t does not match the block counts of the system");
+    if (d.kind != KKT_PC_STATIONARY && n_ < 2) fail(KKT_ERR_ARG, "need at least two blocks");
+    if (d.mass_its < 0 || d.schur_its < 0) fail(KKT_ERR_ARG, "negative Chebyshev degree");
+    if ((d.mass_its > 0 && !(d.mass_emax > d.mass_emin && d.mass_emin > 0)) ||
+        (d.schur_its > 0 && !(d.schur_emax > d.schur_emin && d.schur_emin > 0)))
+        fail(KKT_ERR_ARG, "Chebyshev bounds must satisfy 0 < emin < emax");
+    // deep copies: the caller's arrays are not kept (kkt.h conventions)
+    m_indptr_.assign(d.m_indptr, d.m_indptr + nx_ + 1);
+    m_indices_.assign(d.m_indices, d.m_indices + m_indptr_[nx_]);
+    m_values_.assign(d.m_values, d.m_values + m_indptr_[nx_]);
+    if (d.n_bc > 0) bc_idx_.assign(d.bc_idx, d.bc_idx + d.n_bc);
+    d_.m_indptr = d_.m_indices = nullptr;
+    d_.m_values = nullptr;
+    d_.bc_idx = nullptr;
+    const char *e = std::getenv("KKT_NO_GRAPH");
+    use_graph_ = !(e && e[0] == '1');
+    build();
+}
+
+SchurPC::~SchurPC() {
+    clear_program();
+    for (void *p : owned_)
+        if (p) (void)hipFree(p);
+}
+
+void SchurPC::clear_program() {
+    if (exec_) (void)hipGraphExecDestroy(exec_);
+    if (graph_) (void)hipGraphDestroy(graph_);
+    exec_ = nullptr;
+    graph_ = nullptr;
+    for (auto &s : steps_)
+        if (s.kind == PcStep::ROWS && s.rows.d_ops) (void)hipFree(s.rows.d_ops);
+    steps_.clear();
+}
+
+void SchurPC::values_changed() {
+    // Schur matrices are sums with block values: rebuild them and the program
+    clear_program();
+    for (auto &kv : mats_) {
+        (void)hipFree(kv.second.vals);
+        (void)hipFree(kv.second.dinv);
+    }
+    mats_.clear();
+    if (d_.kind == KKT_PC_STATIONARY)
+        build_stationary();
+    else if (d_.kind == KKT_PC_INSTATIONARY_BE)
+        build_BE();
+    else
+        build_CN();
+}
+
+const double *SchurPC::block_vals(int q, int i, int j) const {
+    auto it = S_.blocks.find(std::make_tuple(q, i, j));
+    if (it == S_.blocks.end())
+        fail(KKT_ERR_STATE, "preconditioner needs block (" + std::to_string(q) + "," +
+                                std::to_string(i) + "," + std::to_string(j) + ")");
+    const ValueArray &va = S_.values[it->second.va];
+    if (va.pattern != m_pat_)
+        fail(KKT_ERR_STATE, "preconditioner blocks must share the mass matrix's sparsity");
+    return va.d_vals;
+}
+
+void SchurPC::build() {
+    hipStream_t st = S_.stream;
+    bc_set_ = bc_idx_.empty() ? -1 : S_.add_bc_set(nx_, (int64_t)bc_idx_.size(), bc_idx_.data());
+    mask_ = bc_set_ >= 0 ? S_.bc_sets[bc_set_].d_mask : nullptr;
+    m_pat_ = S_.find_or_add_pattern(nx_, nx_, m_indptr_.data(), m_indices_.data());
+    const Pattern &P = S_.patterns[m_pat_];
+    {
+        double *d_csr = dev_upload(m_values_.data(), m_values_.size());
+        m_vals_ = dev_alloc<double>(P.npadded);
+        owned_.push_back(m_vals_);
+        launch_csr_to_sell(st, d_csr, P.d_sell2csr, m_vals_, P.npadded);
+        if (mask_) launch_mask_columns(st, m_vals_, P.d_col, mask_, P.npadded);
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipFree(d_csr));
+    }
+    m_dinv_ = dev_alloc<double>(nx_);
+    owned_.push_back(m_dinv_);
+    launch_extract_dinv(st, P.d_col, P.d_slice_off, m_vals_, mask_, m_dinv_, (int)nx_, P.nslices,
+                        P.R);
+    {
+        std::vector<int32_t> z(P.nslices + 1, 0);
+        zero_off_ = dev_upload(z.data(), z.size());
+        owned_.push_back(zero_off_);
+    }
+    auto vec = [&](int64_t blocks) {
+        double *p = dev_alloc<double>(blocks * nx_ + 32);
+        HIPCHK(hipMemsetAsync(p, 0, (blocks * nx_ + 32) * sizeof(double), st));
+        owned_.push_back(p);
+        return p;
+    };
+    in_ = vec(2 * n_);
+    out_ = vec(2 * n_);
+    B_ = vec(n_);
+    T_ = vec(n_);
+    for (int k = 0; k < 3; ++k) P_[k] = vec(n_);
+    values_changed();
+}
+
+// base + c * M with bc rows/cols of `assemble(form, bcs=...)`, and its Jacobi diagonal
+SchurPC::Mat SchurPC::schur_matrix(const double *base_vals, double c) {
+    uint64_t bits;
+    std::memcpy(&bits, &c, sizeof bits);
+    auto key = std::make_pair(base_vals, bits);
+    auto it = mats_.find(key);
+    if (it != mats_.end()) return it->second;
+    const Pattern &P = S_.patterns[m_pat_];
+    hipStream_t st = S_.stream;
+    Mat m;
+    m.vals = dev_alloc<double>(P.npadded);
+    m.dinv = dev_alloc<double>(nx_);
+    launch_vals_axpy(st, m.vals, base_vals, c, m_vals_, P.npadded);
+    if (mask_) launch_mask_columns(st, m.vals, P.d_col, mask_, P.npadded);
+    launch_extract_dinv(st, P.d_col, P.d_slice_off, m.vals, mask_, m.dinv, (int)nx_, P.nslices,
+                        P.R);
+    mats_[key] = m;
+    return m;
+}
+
+void SchurPC::emit_lin(const std::vector<Lin> &ops) {
+    const Pattern &P = S_.patterns[m_pat_];
+    std::vector<RowOp> r;
+    for (const Lin &l : ops) {
+        if ((int)l.terms.size() > MAX_TERMS) fail(KKT_ERR_STATE, "too many terms");
+        RowOp op{};
+        op.col = P.d_col;
+        op.slice_off = l.terms.empty() ? zero_off_ : P.d_slice_off;
+        op.nrows = (int32_t)nx_;
+        op.nslices = P.nslices;
+        op.nterms = (int32_t)l.terms.size();
+        op.mode = EPI_LIN;
+        for (size_t t = 0; t < l.terms.size(); ++t) {
+            op.t[t].vals = l.terms[t].vals;
+            op.t[t].x = vabs(l.terms[t].x);
+        }
+        op.y = vabs(l.y);
+        op.ca = l.ca;
+        op.cy = l.cy;
+        op.cz = l.cz;
+        op.yin = vabs(l.yin);
+        op.z = vabs(l.z);
+        op.rowmask = mask_;
+        op.mx = vabs(nullptr);
+        op.b = op.pk = op.pkm1 = vabs(nullptr);
+        r.push_back(op);
+    }
+    PcStep s;
+    s.kind = PcStep::ROWS;
+    s.rows.nops = (int)r.size();
+    s.rows.max_slices = P.nslices;
+    s.rows.R = P.R;
+    s.rows.d_ops = dev_upload(r.data(), r.size());
+    steps_.push_back(s);
+}
+
+void SchurPC::emit_cheb(const std::vector<Cheb> &ops) {
+    const Pattern &P = S_.patterns[m_pat_];
+    std::vector<RowOp> r;
+    for (const Cheb &c : ops) {
+        RowOp op{};
+        op.col = P.d_col;
+        op.slice_off = c.vals ? P.d_slice_off : zero_off_;
+        op.nrows = (int32_t)nx_;
+        op.nslices = P.nslices;
+        op.nterms = c.vals ? 1 : 0;
+        op.mode = EPI_CHEB;
+        if (c.vals) {
+            op.t[0].vals = c.vals;
+            op.t[0].x = vabs(c.pk);
+        }
+        op.y = vabs(c.y);
+        op.yin = op.z = op.mx = vabs(nullptr);
+        op.rowmask = mask_;
+        op.b = vabs(c.b);
+        op.pk = vabs(c.pk);
+        op.pkm1 = vabs(c.pkm1);
+        op.dinv = c.dinv;
+        op.c1 = c.c1;
+        op.c2 = c.c2;
+        op.c3 = c.c3;
+        op.post1 = c.post1;
+        op.post2 = c.post2;
+        r.push_back(op);
+    }
+    PcStep s;
+    s.kind = PcStep::ROWS;
+    s.rows.nops = (int)r.size();
+    s.rows.max_slices = P.nslices;
+    s.rows.R = P.R;
+    s.rows.d_ops = dev_upload(r.data(), r.size());
+    steps_.push_back(s);
+}
+
+void SchurPC::emit_time(double *y, const double *x, int kind, int n) {
+    PcStep s;
+    s.kind = PcStep::TIME;
+    s.y = y;
+    s.x = x;
+    s.tkind = kind;
+    s.n = n;
+    s.nx = nx_;
+    steps_.push_back(s);
+}
+
+// KSPSolve_Chebyshev (first kind) + PCJACOBI, zero initial guess, exactly `its` steps
+// (options of control.py:1973-1982); its == 0: one Jacobi application (control.py:1984-1991).
+void SchurPC::emit_solves(const std::vector<Solve> &sv, int its, double emin, double emax,
+                          double *const P[3], int64_t pstride) {
+    const size_t m = sv.size();
+    std::vector<Cheb> ops(m);
+    if (its == 0) {
+        for (size_t q = 0; q < m; ++q)
+            ops[q] = Cheb{nullptr, sv[q].dinv, sv[q].b, nullptr, nullptr, sv[q].out,
+                          0.0, 0.0, 1.0, sv[q].post1, sv[q].post2};
+        emit_cheb(ops);
+        return;
+    }
+    const double scale = 2.0 / (emax + emin);
+    const double alpha = 1.0 - scale * emin;
+    const double mu = 1.0 / alpha;
+    const double omegaprod = 2.0 / alpha;
+    double c_km1 = 1.0, c_k = mu;
+    // step 1: p_1 = scale * D^-1 b
+    auto target = [&](int step, size_t q) -> double * {
+        return step == its ? sv[q].out : P[(step - 1) % 3] + (int64_t)q * pstride;
+    };
+    for (size_t q = 0; q < m; ++q) {
+        const bool last = its == 1;
+        ops[q] = Cheb{nullptr, sv[q].dinv, sv[q].b, nullptr, nullptr, target(1, q),
+                      0.0, 0.0, scale, last ? sv[q].post1 : 1.0, last ? sv[q].post2 : 1.0};
+    }
+    emit_cheb(ops);
+    for (int step = 2; step <= its; ++step) {
+        const double c_kp1 = 2.0 * mu * c_k - c_km1;
+        const double omega = omegaprod * c_k / c_kp1;
+        const bool last = step == its;
+        for (size_t q = 0; q < m; ++q) {
+            const double *pk = target(step - 1, q);
+            const double *pkm1 = step >= 3 ? target(step - 2, q) : nullptr;
+            ops[q] = Cheb{sv[q].vals, sv[q].dinv, sv[q].b, pk, pkm1, target(step, q),
+                          1.0 - omega, omega, scale * omega,
+                          last ? sv[q].post1 : 1.0, last ? sv[q].post2 : 1.0};
+        }
+        emit_cheb(ops);
+        c_km1 = c_k;
+        c_k = c_kp1;
+    }
+}
+
+// ---- Control.Stationary.construct_pc, control.py:356-448
+void SchurPC::build_stationary() {
+    const double c = 1.0 / std::sqrt(d_.beta);
+    const double *Dv = block_vals(KKT_Q10, 0, 0);
+    const double *Dz = block_vals(KKT_Q01, 0, 0);
+    double *b0 = in_, *b1 = in_ + nx_;
+    double *u0 = out_, *u1 = out_ + nx_;
+    emit_solves({Solve{m_vals_, m_dinv_, b0, u0}}, d_.mass_its, d_.mass_emin, d_.mass_emax, P_, nx_);
+    emit_lin({Lin{{Term{Dv, u0}}, B_, 1.0, 0.0, -1.0, nullptr, b1}});
+    Mat S1 = schur_matrix(Dv, c), S2 = schur_matrix(Dz, c);
+    emit_solves({Solve{S1.vals, S1.dinv, B_, u1}}, d_.schur_its, d_.schur_emin, d_.schur_emax, P_, nx_);
+    emit_lin({Lin{{Term{m_vals_, u1}}, B_, 1.0}});
+    emit_solves({Solve{S2.vals, S2.dinv, B_, u1}}, d_.schur_its, d_.schur_emin, d_.schur_emax, P_, nx_);
+}
+
+// ---- Control.Instationary.construct_pc, BE branch, control.py:2191-2438
+void SchurPC::build_BE() {
+    const int n = n_;
+    const double tau = d_.tau, eps = d_.epsilon;
+    const double shift = tau / std::sqrt(d_.beta);
+    double *b0 = in_, *b1 = in_ + (int64_t)n * nx_;
+    double *u0 = out_, *u1 = out_ + (int64_t)n * nx_;
+    auto blk = [&](double *base, int i) { return base + (int64_t)i * nx_; };
+    // (1,1)-block: u0_i = (1/tau) M~^-1 b0_i, last one also / epsilon   (2193-2206)
+    {
+        std::vector<Solve> sv;
+        for (int i = 0; i < n; ++i)
+            sv.push_back(Solve{m_vals_, m_dinv_, blk(b0, i), blk(u0, i), 1.0 / tau,
+                               i == n - 1 ? 1.0 / eps : 1.0});
+        emit_solves(sv, d_.mass_its, d_.mass_emin, d_.mass_emax, P_, nx_);
+    }
+    // b_i = block_10(i,i) u0_i + block_10(i,i-1) u0_{i-1} - b1_i   (2208-2237)
+    {
+        std::vector<Lin> ops;
+        for (int i = 0; i < n; ++i) {
+            Lin l;
+            l.terms.push_back(Term{block_vals(KKT_Q10, i, i), blk(u0, i)});
+            if (i >= 1) l.terms.push_back(Term{block_vals(KKT_Q10, i, i - 1), blk(u0, i - 1)});
+            l.y = blk(B_, i);
+            l.cz = -1.0;
+            l.z = blk(b1, i);
+            ops.push_back(l);
+        }
+        emit_lin(ops);
+    }
+    auto coef = [&](int i) { return i == 0 ? 0.0 : (i == n - 1 ? std::sqrt(eps) * shift : shift); };
+    // forward sweep (2241-2327)
+    for (int i = 0; i < n; ++i) {
+        if (i >= 1)
+            emit_lin({Lin{{Term{block_vals(KKT_Q10, i, i - 1), blk(u1, i - 1)}}, blk(B_, i), -1.0,
+                          1.0, 0.0, blk(B_, i), nullptr}});
+        Mat F = schur_matrix(block_vals(KKT_Q10, i, i), coef(i));
+        emit_solves({Solve{F.vals, F.dinv, blk(B_, i), blk(u1, i)}}, d_.schur_its, d_.schur_emin,
+                    d_.schur_emax, P_, nx_);
+    }
+    // b_i = tau M u1_i (epsilon tau for the last)   (2330-2350)
+    {
+        std::vector<Lin> ops;
+        for (int i = 0; i < n; ++i)
+            ops.push_back(Lin{{Term{m_vals_, blk(u1, i)}}, blk(B_, i),
+                              i == n - 1 ? eps * tau : tau});
+        emit_lin(ops);
+    }
+    // backward sweep (2353-2437)
+    for (int i = n - 1; i >= 0; --i) {
+        if (i <= n - 2)
+            emit_lin({Lin{{Term{block_vals(KKT_Q01, i, i + 1), blk(u1, i + 1)}}, blk(B_, i), -1.0,
+                          1.0, 0.0, blk(B_, i), nullptr}});
+        Mat G = schur_matrix(block_vals(KKT_Q01, i, i), coef(i));
+        emit_solves({Solve{G.vals, G.dinv, blk(B_, i), blk(u1, i)}}, d_.schur_its, d_.schur_emin,
+                    d_.schur_emax, P_, nx_);
+    }
+}
+
+// ---- Control.Instationary.construct_pc, CN branch, control.py:1995-2189
+void SchurPC::build_CN() {
+    const int n = n_;
+    const double tau = d_.tau;
+    const double c = 0.5 * tau / std::sqrt(d_.beta);   // my_const, control.py:2051
+    double *b0 = in_, *b1 = in_ + (int64_t)n * nx_;
+    double *u0 = out_, *u1 = out_ + (int64_t)n * nx_;
+    auto blk = [&](double *base, int i) { return base + (int64_t)i * nx_; };
+    Mat cM = schur_matrix(nullptr, c);   // c * M~ (base absent): products with my_const * M
+    // (1,1)-block (1997-2014)
+    emit_time(T_, b0, 3, n);   // T_1^-1
+    {
+        std::vector<Solve> sv;
+        for (int i = 0; i < n; ++i)
+            sv.push_back(Solve{m_vals_, m_dinv_, blk(T_, i), blk(u0, i), 2.0 / tau, 1.0});
+        emit_solves(sv, d_.mass_its, d_.mass_emin, d_.mass_emax, P_, nx_);
+    }
+    emit_time(u0, u0, 4, n);   // T_2^-1
+    // b = T_2 (D_v u0) - b1 (2016-2048)
+    {
+        std::vector<Lin> ops;
+        for (int i = 0; i < n; ++i) {
+            Lin l;
+            l.terms.push_back(Term{block_vals(KKT_Q10, i, i), blk(u0, i)});
+            if (i >= 1) l.terms.push_back(Term{block_vals(KKT_Q10, i, i - 1), blk(u0, i - 1)});
+            l.y = blk(B_, i);
+            ops.push_back(l);
+        }
+        emit_lin(ops);
+    }
+    emit_time(B_, B_, 2, n);
+    {
+        std::vector<Lin> ops;
+        for (int i = 0; i < n; ++i)
+            ops.push_back(Lin{{}, blk(B_, i), 0.0, 1.0, -1.0, blk(B_, i), blk(b1, i)});
+        emit_lin(ops);
+    }
+    // forward sweep (2050-2116)
+    emit_time(B_, B_, 4, n);
+    for (int i = 0; i < n; ++i) {
+        if (i >= 1)
+            emit_lin({Lin{{Term{block_vals(KKT_Q10, i, i - 1), blk(u1, i - 1)},
+                           Term{cM.vals, blk(u1, i - 1)}},
+                          blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i), nullptr}});
+        Mat F = schur_matrix(block_vals(KKT_Q10, i, i), c);
+        emit_solves({Solve{F.vals, F.dinv, blk(B_, i), blk(u1, i)}}, d_.schur_its, d_.schur_emin,
+                    d_.schur_emax, P_, nx_);
+    }
+    // u1 = T_2 u1; b_i = (tau/2) M u1_i (2118-2133)
+    emit_time(u1, u1, 2, n);
+    {
+        std::vector<Lin> ops;
+        for (int i = 0; i < n; ++i)
+            ops.push_back(Lin{{Term{m_vals_, blk(u1, i)}}, blk(B_, i), 0.5 * tau});
+        emit_lin(ops);
+    }
+    // backward sweep (2135-2189)
+    for (int i = n - 1; i >= 0; --i) {
+        if (i <= n - 2) {
+            Mat H = schur_matrix(block_vals(KKT_Q01, i, i + 1), c);
+            emit_lin({Lin{{Term{H.vals, blk(u1, i + 1)}}, blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i),
+                          nullptr}});
+        }
+        Mat G = schur_matrix(block_vals(KKT_Q01, i, i), c);
+        emit_solves({Solve{G.vals, G.dinv, blk(B_, i), blk(u1, i)}}, d_.schur_its, d_.schur_emin,
+                    d_.schur_emax, P_, nx_);
+    }
+}
+
+void SchurPC::replay() {
+    hipStream_t st = S_.stream;
+    Bases B{{nullptr, nullptr, nullptr, nullptr}};
+    for (const PcStep &s : steps_) {
+        switch (s.kind) {
+            case PcStep::ROWS:
+                launch_rowops(st, s.rows.d_ops, s.rows.nops, s.rows.max_slices, s.rows.R, B, 1);
+                break;
+            case PcStep::TIME:
+                launch_time_transform(st, s.y, s.x, s.tkind, s.n, s.nx, nullptr, nullptr);
+                break;
+            case PcStep::COPY:
+                launch_copy(st, s.y, s.x, s.nx);
+                break;
+        }
+    }
+}
+
+void SchurPC::run() {
+    hipStream_t st = S_.stream;
+    if (use_graph_ && !exec_) {
+        // the program is a fixed launch sequence on fixed buffers: capture it once
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            replay();
+            e = hipStreamEndCapture(st, &graph_);
+            if (e == hipSuccess) e = hipGraphInstantiate(&exec_, graph_, nullptr, nullptr, 0);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            exec_ = nullptr;
+            use_graph_ = false;   // plain launches of the same kernels
+        }
+    }
+    if (exec_)
+        HIPCHK(hipGraphLaunch(exec_, st));
+    else
+        replay();
+}
+
+}  // namespace kkt

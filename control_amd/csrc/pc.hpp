@@ -1,0 +1,97 @@
+// Built-in block Schur-complement preconditioner on the GPU: the `pc_linear` closures of
+// Control.Stationary.construct_pc (reference control/control.py:351-450) and
+// Control.Instationary.construct_pc (control.py:1943-2440).
+#pragma once
+#include <map>
+#include <vector>
+
+#include "system.hpp"
+
+namespace kkt {
+
+struct PcStep {
+    enum Kind { ROWS, TIME, COPY } kind;
+    RowLaunch rows;                 // ROWS
+    double *y = nullptr;            // TIME / COPY
+    const double *x = nullptr;
+    int tkind = 0, n = 0;
+    int64_t nx = 0;                 // TIME: block length; COPY: element count
+};
+
+class SchurPC {
+   public:
+    SchurPC(System &S, const kkt_pc_desc &d);
+    ~SchurPC();
+    // u = pc_fn(b) on the fixed internal vectors in_ / out_ (bc-corrected by the caller)
+    void run();
+    double *in() { return in_; }
+    double *out() { return out_; }
+    void values_changed();
+    int bc_set() const { return bc_set_; }
+    int64_t n_launches() const { return (int64_t)steps_.size(); }
+
+   private:
+    System &S_;
+    kkt_pc_desc d_;
+    std::vector<int32_t> m_indptr_, m_indices_, bc_idx_;
+    std::vector<double> m_values_;
+    int n_ = 1;                // blocks per variable
+    int64_t nx_ = 0;
+    int bc_set_ = -1;
+    const uint8_t *mask_ = nullptr;
+    int m_pat_ = -1;
+    double *m_vals_ = nullptr;           // bc-assembled M (cols masked)
+    double *m_dinv_ = nullptr;
+    int32_t *zero_off_ = nullptr;
+    double *in_ = nullptr, *out_ = nullptr;
+    double *B_ = nullptr, *T_ = nullptr;             // n_ blocks each
+    double *P_[3] = {nullptr, nullptr, nullptr};     // Chebyshev rotation, n_ blocks each
+    std::vector<void *> owned_;                      // device allocations to free
+    struct Mat {
+        double *vals;
+        double *dinv;
+    };
+    std::map<std::pair<const double *, uint64_t>, Mat> mats_;
+    std::vector<PcStep> steps_;
+    hipGraph_t graph_ = nullptr;
+    hipGraphExec_t exec_ = nullptr;
+    bool use_graph_ = true;
+
+    struct Term {
+        const double *vals;
+        const double *x;
+    };
+    struct Lin {   // y = mask(ca * sum_t A_t x_t + cy * yin + cz * z)
+        std::vector<Term> terms;
+        double *y;
+        double ca = 1.0, cy = 0.0, cz = 0.0;
+        const double *yin = nullptr, *z = nullptr;
+    };
+    struct Cheb {
+        const double *vals;   // nullptr: no matrix term (first step)
+        const double *dinv, *b, *pk, *pkm1;
+        double *y;
+        double c1, c2, c3, post1 = 1.0, post2 = 1.0;
+    };
+    void build();
+    void clear_program();
+    const double *block_vals(int q, int i, int j) const;
+    Mat schur_matrix(const double *base_vals, double c);
+    void emit_lin(const std::vector<Lin> &ops);
+    void emit_cheb(const std::vector<Cheb> &ops);
+    void emit_time(double *y, const double *x, int kind, int n);
+    // its-step Jacobi-Chebyshev solves of `count` independent systems in lock step
+    struct Solve {
+        const double *vals, *dinv, *b;
+        double *out;
+        double post1 = 1.0, post2 = 1.0;
+    };
+    void emit_solves(const std::vector<Solve> &sv, int its, double emin, double emax,
+                     double *const P[3], int64_t pstride);
+    void build_stationary();
+    void build_BE();
+    void build_CN();
+    void replay();
+};
+
+}  // namespace kkt

@@ -1,0 +1,583 @@
+// Block system: definition, HBM layout (SELL-64R with shared index arrays), KKT apply.
+// Restates MultiBlockSystem.__init__ / MultiBlockSystemMatrix.mult
+// (reference preconditioner/preconditioner.py:216-335, 375-543) for the GPU.
+#include "system.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "comm.hpp"
+#include "pc.hpp"
+
+namespace kkt {
+
+void fail(int code, const std::string &msg) { throw Error{code, msg}; }
+
+void hip_check(hipError_t e, const char *what, const char *file, int line) {
+    if (e != hipSuccess) {
+        fail(KKT_ERR_HIP, std::string(hipGetErrorString(e)) + " in " + what + " at " + file +
+                              ":" + std::to_string(line));
+    }
+}
+
+System::~System() {
+    // device memory is released with the process or by hipDeviceReset; explicit frees keep
+    // long-lived hosts (Picard loops creating many systems) from accumulating HBM
+    (void)hipSetDevice(device);
+    pc.reset();
+    comm.reset();
+    auto F = [](void *p) {
+        if (p) (void)hipFree(p);
+    };
+    for (auto &p : patterns) {
+        F(p.d_col);
+        F(p.d_slice_off);
+        F(p.d_sell2csr);
+    }
+    for (auto &v : values) F(v.d_vals);
+    for (auto &b : bc_sets) {
+        F(b.d_mask);
+        F(b.d_idx);
+    }
+    for (auto &l : apply_launches) F(l.d_ops);
+    F(d_mask_jobs);
+    F(d_mask_jobs_one);
+    F(d_pc_in);
+    F(d_pc_out);
+    F(d_rhs);
+    F(d_xc);
+    F(d_tmp_y);
+    F(d_sums);
+    F(d_halo_x0_lo);
+    F(d_halo_x1_hi);
+    F(d_halo_r0_hi);
+    F(d_halo_r1_lo);
+    F(d_V);
+    F(d_Z);
+    F(d_w);
+    F(d_t1);
+    F(d_t2);
+    F(d_red_scratch);
+    F(d_hcol);
+    F(d_coef);
+    if (h_pinned) (void)hipHostFree(h_pinned);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+void System::set_layout(int n_blocks_00, int n_blocks_11, int64_t nx0_, int64_t nx1_, int CN_,
+                        int s00, int s11) {
+    if (layout_set) fail(KKT_ERR_STATE, "layout already set");
+    if (n_blocks_00 < 1 || n_blocks_11 < 1 || nx0_ < 1 || nx1_ < 1)
+        fail(KKT_ERR_ARG, "block counts and sizes must be positive");
+    if (nx0_ >= (int64_t)1 << 31 || nx1_ >= (int64_t)1 << 31)
+        fail(KKT_ERR_ARG, "spatial block size exceeds int32 indexing");
+    if ((s00 >= 0) != (s11 >= 0))
+        fail(KKT_ERR_ARG, "sub_n_blocks_00_0 and sub_n_blocks_11_0 must be given together");
+    if (s00 > n_blocks_00 || s11 > n_blocks_11) fail(KKT_ERR_ARG, "sub_n_blocks out of range");
+    n0 = n_blocks_00;
+    n1 = n_blocks_11;
+    nx0 = nx0_;
+    nx1 = nx1_;
+    CN = CN_ != 0;
+    sub00 = s00;
+    sub11 = s11;
+    n0_loc = n0;
+    n1_loc = n1;
+    nullspaces.assign(n0 + n1, NullspaceSpec{});
+    layout_set = true;
+    const char *e = std::getenv("KKT_SELL_R");
+    if (e && (e[0] == '1' || e[0] == '2')) sell_R = e[0] - '0';
+}
+
+void System::set_shard(int rank_, int world_) {
+    if (!layout_set || finalized || !blocks.empty())
+        fail(KKT_ERR_STATE, "kkt_set_shard must follow kkt_set_layout and precede blocks");
+    if (world_ < 1 || rank_ < 0 || rank_ >= world_) fail(KKT_ERR_ARG, "bad rank/world");
+    if (world_ == 1) return;
+    if (n0 != n1) fail(KKT_ERR_ARG, "time sharding needs n_blocks_00 == n_blocks_11");
+    if (sub00 >= 0) fail(KKT_ERR_ARG, "time sharding with sub-block splits is not supported");
+    if (world_ > n0) fail(KKT_ERR_ARG, "more ranks than time-block rows");
+    rank = rank_;
+    world = world_;
+    kkt_shard_range(n0, rank, world, &lo, &hi);
+    sharded = true;
+    n0_loc = n1_loc = hi - lo;
+}
+
+static uint64_t fnv1a(const void *data, size_t bytes, uint64_t h) {
+    const unsigned char *p = static_cast<const unsigned char *>(data);
+    for (size_t i = 0; i < bytes; ++i) {
+        h ^= p[i];
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+int System::find_or_add_pattern(int64_t nrows, int64_t ncols, const int32_t *indptr,
+                                const int32_t *indices) {
+    const int64_t nnz = indptr[nrows];
+    uint64_t h = 1469598103934665603ull;
+    h = fnv1a(&nrows, sizeof nrows, h);
+    h = fnv1a(&ncols, sizeof ncols, h);
+    h = fnv1a(indptr, (nrows + 1) * sizeof(int32_t), h);
+    h = fnv1a(indices, nnz * sizeof(int32_t), h);
+    for (size_t p = 0; p < patterns.size(); ++p) {
+        const Pattern &P = patterns[p];
+        if (P.hash == h && P.nrows == nrows && P.ncols == ncols && P.nnz == nnz &&
+            std::memcmp(P.h_indptr.data(), indptr, (nrows + 1) * sizeof(int32_t)) == 0 &&
+            std::memcmp(P.h_indices.data(), indices, nnz * sizeof(int32_t)) == 0)
+            return (int)p;
+    }
+    Pattern P;
+    P.nrows = nrows;
+    P.ncols = ncols;
+    P.nnz = nnz;
+    P.hash = h;
+    P.R = sell_R;
+    P.h_indptr.assign(indptr, indptr + nrows + 1);
+    P.h_indices.assign(indices, indices + nnz);
+    const int C = 64 * P.R;
+    P.nslices = (int)((nrows + C - 1) / C);
+    std::vector<int32_t> off(P.nslices + 1, 0);
+    for (int s = 0; s < P.nslices; ++s) {
+        int w = 0;
+        const int64_t r1 = std::min<int64_t>(nrows, (int64_t)(s + 1) * C);
+        for (int64_t r = (int64_t)s * C; r < r1; ++r) {
+            if (indptr[r + 1] < indptr[r]) fail(KKT_ERR_ARG, "indptr not monotone");
+            w = std::max(w, indptr[r + 1] - indptr[r]);
+        }
+        P.max_width = std::max(P.max_width, w);
+        off[s + 1] = off[s] + w;
+    }
+    P.nslots = off[P.nslices];
+    P.npadded = P.nslots * C;
+    if (P.npadded >= (int64_t)1 << 31) fail(KKT_ERR_ARG, "block too large for int32 maps");
+    std::vector<int32_t> col(P.npadded), map(P.npadded, -1);
+    for (int s = 0; s < P.nslices; ++s) {
+        const int w = off[s + 1] - off[s];
+        for (int within = 0; within < C; ++within) {
+            const int64_t r = (int64_t)s * C + within;
+            const int32_t self = (int32_t)std::min<int64_t>(std::min<int64_t>(r, nrows - 1),
+                                                            ncols - 1);
+            const int len = r < nrows ? indptr[r + 1] - indptr[r] : 0;
+            for (int k = 0; k < w; ++k) {
+                const int64_t p = ((int64_t)off[s] + k) * C + within;
+                if (k < len) {
+                    const int32_t c = indices[indptr[r] + k];
+                    if (c < 0 || c >= ncols) fail(KKT_ERR_ARG, "column index out of range");
+                    if (k > 0 && c <= indices[indptr[r] + k - 1])
+                        fail(KKT_ERR_ARG, "column indices must be sorted and unique in a row");
+                    col[p] = c;
+                    map[p] = indptr[r] + k;
+                } else {
+                    col[p] = self;   // padding: value 0, gather stays local
+                }
+            }
+        }
+    }
+    P.d_col = dev_upload(col.data(), col.size());
+    P.d_slice_off = dev_upload(off.data(), off.size());
+    P.d_sell2csr = dev_upload(map.data(), map.size());
+    patterns.push_back(std::move(P));
+    info.bytes_device_index += patterns.back().npadded * 4 + (patterns.back().nslices + 1) * 4;
+    return (int)patterns.size() - 1;
+}
+
+int System::new_value_array(int pattern, const double *csr_vals) {
+    const Pattern &P = patterns[pattern];
+    ValueArray va;
+    va.pattern = pattern;
+    va.d_vals = dev_alloc<double>(P.npadded);
+    double *d_csr = dev_upload(csr_vals, (size_t)P.nnz);
+    launch_csr_to_sell(stream, d_csr, P.d_sell2csr, va.d_vals, P.npadded);
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipFree(d_csr));
+    values.push_back(va);
+    info.bytes_device_values += P.npadded * 8;
+    return (int)values.size() - 1;
+}
+
+void System::add_block(int q, int i, int j, int64_t nrows, int64_t ncols,
+                       const int32_t *indptr, const int32_t *indices, const double *vals,
+                       int64_t share_id) {
+    if (!layout_set || finalized) fail(KKT_ERR_STATE, "kkt_add_block: wrong state");
+    if (q < 0 || q > 3 || !indptr || !indices || !vals) fail(KKT_ERR_ARG, "bad block args");
+    const int nr = (q == KKT_Q00 || q == KKT_Q01) ? n0 : n1;
+    const int nc = (q == KKT_Q00 || q == KKT_Q10) ? n0 : n1;
+    const int64_t er = (q == KKT_Q00 || q == KKT_Q01) ? nx0 : nx1;
+    const int64_t ec = (q == KKT_Q00 || q == KKT_Q10) ? nx0 : nx1;
+    if (i < 0 || i >= nr || j < 0 || j >= nc) fail(KKT_ERR_ARG, "block index out of range");
+    if (nrows != er || ncols != ec) fail(KKT_ERR_ARG, "block shape does not match the layout");
+    if (sharded) {
+        if (i < lo || i >= hi) fail(KKT_ERR_ARG, "block row not owned by this rank");
+        if (j < lo - 1 || j > hi) fail(KKT_ERR_ARG, "time sharding needs |i - j| <= 1 blocks");
+    }
+    auto key = std::make_tuple(q, i, j);
+    if (blocks.count(key)) fail(KKT_ERR_ARG, "block added twice");
+    int va = -1;
+    if (share_id >= 0) {
+        auto it = share_map.find(share_id);
+        if (it != share_map.end()) {
+            va = it->second;
+            const Pattern &P = patterns[values[va].pattern];
+            if (P.nrows != nrows || P.ncols != ncols || P.nnz != indptr[nrows])
+                fail(KKT_ERR_ARG, "share_id reused for a block of different structure");
+        }
+    }
+    if (va < 0) {
+        const int p = find_or_add_pattern(nrows, ncols, indptr, indices);
+        va = new_value_array(p, vals);
+        values[va].share_id = share_id;
+        if (share_id >= 0) share_map[share_id] = va;
+        info.n_value_arrays++;
+        info.bytes_algorithmic += 12 * patterns[p].nnz + 4 * (nrows + 1);
+    }
+    blocks[key] = Block{q, i, j, va, order_counter[q]++};
+    info.n_blocks_stored++;
+    info.nnz_blocks += indptr[nrows];
+    info.rows_blocks += nrows;
+}
+
+int System::add_bc_set(int64_t nx, int64_t n, const int32_t *idx) {
+    std::vector<int32_t> v(idx, idx + n);
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    for (int32_t k : v)
+        if (k < 0 || k >= nx) fail(KKT_ERR_ARG, "Dirichlet dof index out of range");
+    for (size_t s = 0; s < bc_sets.size(); ++s)
+        if (bc_sets[s].nx == nx && bc_sets[s].idx == v) return (int)s;
+    BcSet b;
+    b.nx = nx;
+    b.idx = v;
+    std::vector<uint8_t> m(nx, 0);
+    for (int32_t k : v) m[k] = 1;
+    b.d_mask = dev_upload(m.data(), m.size());
+    b.d_idx = dev_upload(v.data(), v.size());
+    bc_sets.push_back(std::move(b));
+    return (int)bc_sets.size() - 1;
+}
+
+void System::set_bc(int k, int64_t n, const int32_t *idx, double alpha) {
+    if (!layout_set || finalized) fail(KKT_ERR_STATE, "kkt_set_bc: wrong state");
+    if (k < 0 || k >= n0 + n1 || n < 0 || (n > 0 && !idx)) fail(KKT_ERR_ARG, "bad bc args");
+    NullspaceSpec ns;
+    ns.kind = 1;
+    ns.alpha = alpha;
+    ns.set_id = add_bc_set(block_nx(k), n, idx);
+    nullspaces[k] = ns;
+}
+
+void System::set_const_ns(int k, double alpha) {
+    if (!layout_set || finalized) fail(KKT_ERR_STATE, "kkt_set_const_nullspace: wrong state");
+    if (k < 0 || k >= n0 + n1) fail(KKT_ERR_ARG, "bad block index");
+    NullspaceSpec ns;
+    ns.kind = 2;
+    ns.alpha = alpha;
+    nullspaces[k] = ns;
+}
+
+double *System::new_vec() {
+    double *p = dev_alloc<double>(vec_stride);
+    HIPCHK(hipMemsetAsync(p, 0, vec_stride * sizeof(double), stream));
+    return p;
+}
+
+static VRef vref(int base, int64_t off) { return VRef{off, base, 0}; }
+static VRef vnull() { return VRef{0, -1, 0}; }
+
+void System::finalize() {
+    if (!layout_set || finalized) fail(KKT_ERR_STATE, "kkt_finalize: wrong state");
+    n_local = (int64_t)n0_loc * nx0 + (int64_t)n1_loc * nx1;
+    vec_stride = (n_local + 31) & ~(int64_t)31;
+    info.n_local = n_local;
+    info.n_patterns = (int64_t)patterns.size();
+    info.bytes_algorithmic += 16 * n_local;
+
+    // ---- column masks: A P of the operator P A P + alpha (I - P) (preconditioner.py:95-103)
+    {
+        std::map<std::pair<int, int>, int> clones;
+        const size_t n_orig = values.size();
+        for (auto &kv : blocks) {
+            Block &b = kv.second;
+            const int colk = (b.q == KKT_Q00 || b.q == KKT_Q10) ? b.j : n0 + b.j;
+            const NullspaceSpec &ns = nullspaces[colk];
+            const int want = ns.kind == 1 ? ns.set_id : -1;
+            ValueArray &va = values[b.va];
+            if (va.colmask_set == -2) {
+                va.colmask_set = want;
+            } else if (va.colmask_set != want) {
+                auto ck = std::make_pair(b.va, want);
+                auto it = clones.find(ck);
+                if (it == clones.end()) {
+                    const Pattern &P = patterns[va.pattern];
+                    ValueArray c = va;
+                    c.d_vals = dev_alloc<double>(P.npadded);
+                    HIPCHK(hipMemcpy(c.d_vals, va.d_vals, P.npadded * 8, hipMemcpyDeviceToDevice));
+                    c.colmask_set = want;
+                    values.push_back(c);
+                    info.bytes_device_values += P.npadded * 8;
+                    it = clones.emplace(ck, (int)values.size() - 1).first;
+                }
+                b.va = it->second;
+            }
+        }
+        (void)n_orig;
+        for (auto &va : values) {
+            if (va.colmask_set >= 0) {
+                const Pattern &P = patterns[va.pattern];
+                launch_mask_columns(stream, va.d_vals, P.d_col, bc_sets[va.colmask_set].d_mask,
+                                    P.npadded);
+            }
+        }
+    }
+
+    any_const_ns = false;
+    for (auto &ns : nullspaces) any_const_ns |= ns.kind == 2;
+    fused_row_masks = !CN;
+
+    // ---- row plan: one RowOp per (row, run of same-pattern terms), chained by accumulation
+    std::vector<std::vector<RowOp>> waves;   // waves[w] = ops of launch w
+    std::vector<int> wave_slices, wave_R;
+    auto put = [&](size_t w, const RowOp &op, int nslices, int R) {
+        if (waves.size() <= w) {
+            waves.resize(w + 1);
+            wave_slices.resize(w + 1, 0);
+            wave_R.resize(w + 1, R);
+        }
+        if (!waves[w].empty() && wave_R[w] != R) fail(KKT_ERR_STATE, "mixed SELL R in a launch");
+        wave_R[w] = R;
+        waves[w].push_back(op);
+        wave_slices[w] = std::max(wave_slices[w], nslices);
+    };
+    for (int var = 0; var < 2; ++var) {
+        const int nloc = var == 0 ? n0_loc : n1_loc;
+        const int64_t nxr = var == 0 ? nx0 : nx1;
+        for (int il = 0; il < nloc; ++il) {
+            const int gi = global_row(var, il);
+            std::vector<const Block *> terms;
+            for (int qq = 0; qq < 2; ++qq) {
+                const int q = var == 0 ? (qq == 0 ? KKT_Q00 : KKT_Q01)
+                                       : (qq == 0 ? KKT_Q10 : KKT_Q11);
+                std::vector<const Block *> row;
+                for (auto &kv : blocks)
+                    if (kv.second.q == q && kv.second.i == gi) row.push_back(&kv.second);
+                std::sort(row.begin(), row.end(),
+                          [](const Block *a, const Block *b) { return a->order < b->order; });
+                terms.insert(terms.end(), row.begin(), row.end());
+            }
+            const int64_t yoff = local_offset(var, il);
+            const int flat_g = var == 0 ? gi : n0 + gi;
+            const NullspaceSpec &rns = nullspaces[flat_g];
+            size_t w = 0;
+            size_t t0 = 0;
+            bool wrote = false;
+            while (t0 < terms.size() || !wrote) {
+                RowOp op{};
+                op.mode = EPI_LIN;
+                op.nrows = (int32_t)nxr;
+                op.y = vref(2, yoff);
+                op.ca = 1.0;
+                op.cy = 1.0;
+                op.cz = 0.0;
+                op.yin = wrote ? vref(2, yoff) : vnull();
+                op.z = vnull();
+                op.mx = vnull();
+                op.b = op.pk = op.pkm1 = vnull();
+                int R = sell_R, nslices = (int)((nxr + 64 * sell_R - 1) / (64 * sell_R));
+                if (t0 < terms.size()) {
+                    const int pat = values[terms[t0]->va].pattern;
+                    const Pattern &P = patterns[pat];
+                    op.col = P.d_col;
+                    op.slice_off = P.d_slice_off;
+                    op.nslices = P.nslices;
+                    R = P.R;
+                    nslices = P.nslices;
+                    int nt = 0;
+                    while (t0 < terms.size() && nt < MAX_TERMS &&
+                           values[terms[t0]->va].pattern == pat) {
+                        const Block *b = terms[t0];
+                        const bool col0 = b->q == KKT_Q00 || b->q == KKT_Q10;
+                        op.t[nt].vals = values[b->va].d_vals;
+                        const int jl = sharded ? b->j - lo : b->j;
+                        const int ncl = col0 ? n0_loc : n1_loc;
+                        if (jl >= 0 && jl < ncl) {
+                            op.t[nt].x = vref(1, local_offset(col0 ? 0 : 1, jl));
+                        } else if (jl < 0) {
+                            op.t[nt].x = vref(3, 0);   // halo below (block lo-1)
+                        } else {
+                            op.t[nt].x = vref(4, 0);   // halo above (block hi)
+                        }
+                        ++nt;
+                        ++t0;
+                    }
+                    op.nterms = nt;
+                } else {
+                    // a row without blocks still produces y = 0 (+ corrections)
+                    op.nterms = 0;
+                    op.nslices = nslices;
+                    op.col = nullptr;
+                    // slice_off of zeros: every slice has width 0
+                    std::vector<int32_t> z(nslices + 1, 0);
+                    op.slice_off = dev_upload(z.data(), z.size());
+                }
+                const bool last = t0 >= terms.size();
+                if (last && fused_row_masks && rns.kind == 1) {
+                    // y = P y + alpha (I - P) x fused into the epilogue (preconditioner.py:
+                    // 527-537).  Bases::p[0] is x after the ConstantNullspace correction, which
+                    // leaves Dirichlet blocks untouched, so it is the original x here.
+                    op.rowmask = bc_sets[rns.set_id].d_mask;
+                    op.mx = vref(1, yoff);
+                    op.malpha = rns.alpha;
+                }
+                put(w, op, nslices, R);
+                wrote = true;
+                ++w;
+            }
+        }
+    }
+    for (size_t w = 0; w < waves.size(); ++w) {
+        RowLaunch L;
+        L.nops = (int)waves[w].size();
+        L.max_slices = wave_slices[w];
+        L.R = wave_R[w];
+        L.d_ops = dev_upload(waves[w].data(), waves[w].size());
+        apply_launches.push_back(L);
+    }
+
+    // ---- CN time transforms (preconditioner.py:437-525)
+    if (CN) {
+        if (sub00 < 0) {
+            time_groups.push_back(TimeGroup{0, n0_loc, 1, nx0});
+            time_groups.push_back(TimeGroup{n0_loc, n1_loc, 2, nx1});
+        } else {
+            time_groups.push_back(TimeGroup{0, sub00, 1, nx0});
+            time_groups.push_back(TimeGroup{sub00, n0 - sub00, 2, nx0});
+            time_groups.push_back(TimeGroup{n0, sub11, 2, nx1});
+            time_groups.push_back(TimeGroup{n0 + sub11, n1 - sub11, 1, nx1});
+        }
+    }
+    // ---- post-correction jobs (Dirichlet) per local flat block, used when not fused
+    {
+        std::vector<MaskJob> jobs;
+        for (int var = 0; var < 2; ++var) {
+            const int nloc = var == 0 ? n0_loc : n1_loc;
+            for (int il = 0; il < nloc; ++il) {
+                const int gi = global_row(var, il);
+                const NullspaceSpec &ns = nullspaces[var == 0 ? gi : n0 + gi];
+                MaskJob j{nullptr, 0.0};
+                if (ns.kind == 1) {
+                    j.mask = bc_sets[ns.set_id].d_mask;
+                    j.alpha = ns.alpha;
+                }
+                jobs.push_back(j);
+            }
+        }
+        d_mask_jobs = dev_upload(jobs.data(), jobs.size());
+        for (auto &j : jobs) j.alpha = 1.0;
+        d_mask_jobs_one = dev_upload(jobs.data(), jobs.size());
+    }
+    if (any_const_ns) {
+        d_xc = new_vec();
+        d_sums = dev_alloc<double>(n0_loc + n1_loc);
+    }
+    if (sharded) {
+        d_halo_x0_lo = dev_alloc<double>(nx0);
+        d_halo_x1_hi = dev_alloc<double>(nx1);
+        HIPCHK(hipMemset(d_halo_x0_lo, 0, nx0 * 8));
+        HIPCHK(hipMemset(d_halo_x1_hi, 0, nx1 * 8));
+        if (CN) {
+            d_halo_r0_hi = dev_alloc<double>(nx0);
+            d_halo_r1_lo = dev_alloc<double>(nx1);
+        }
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    finalized = true;
+}
+
+void System::update_block_values(int q, int i, int j, const double *vals) {
+    if (!finalized) fail(KKT_ERR_STATE, "kkt_update_block_values needs a finalized system");
+    auto it = blocks.find(std::make_tuple(q, i, j));
+    if (it == blocks.end()) fail(KKT_ERR_ARG, "no such block");
+    ValueArray &va = values[it->second.va];
+    const Pattern &P = patterns[va.pattern];
+    double *d_csr = dev_upload(vals, (size_t)P.nnz);
+    launch_csr_to_sell(stream, d_csr, P.d_sell2csr, va.d_vals, P.npadded);
+    if (va.colmask_set >= 0)
+        launch_mask_columns(stream, va.d_vals, P.d_col, bc_sets[va.colmask_set].d_mask, P.npadded);
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipFree(d_csr));
+    if (pc) pc->values_changed();
+}
+
+// y = A x  (preconditioner.py:375-543)
+void System::apply(const double *d_x, double *d_y) {
+    if (!finalized) fail(KKT_ERR_STATE, "system not finalized");
+    info.last_op_applies++;
+    const double *xin = d_x;
+    const int nb = n0_loc + n1_loc;
+    if (any_const_ns) {
+        // x_c = x - mean(x) on ConstantNullspace blocks (preconditioner.py:145-146, 384-393)
+        launch_copy(stream, d_xc, d_x, n_local);
+        for (int var = 0; var < 2; ++var) {
+            const int nloc = var == 0 ? n0_loc : n1_loc;
+            const int64_t nxv = var == 0 ? nx0 : nx1;
+            for (int il = 0; il < nloc; ++il) {
+                const int g = var == 0 ? global_row(0, il) : n0 + global_row(1, il);
+                if (nullspaces[g].kind != 2) continue;
+                double *xb = d_xc + local_offset(var, il);
+                launch_block_sums(stream, xb, d_sums, 1, nxv, nullptr);
+                launch_block_shift(stream, xb, d_sums, -1.0 / (double)nxv, 1, nxv);
+            }
+        }
+        xin = d_xc;
+    }
+    if (sharded) comm_exchange_x_halos(*this, xin);
+    Bases B{{xin, d_y, d_halo_x0_lo, d_halo_x1_hi}};
+    for (const RowLaunch &L : apply_launches)
+        launch_rowops(stream, L.d_ops, L.nops, L.max_slices, L.R, B, 0);
+    if (CN) {
+        if (sharded) comm_exchange_row_halos(*this, d_y);
+        for (const TimeGroup &g : time_groups) {
+            double *yb = d_y + (g.first_local_block < n0_loc
+                                    ? (int64_t)g.first_local_block * nx0
+                                    : (int64_t)n0_loc * nx0 +
+                                          (int64_t)(g.first_local_block - n0_loc) * nx1);
+            const double *lo_h = nullptr, *hi_h = nullptr;
+            if (sharded) {
+                if (g.kind == 1 && hi < n0) hi_h = d_halo_r0_hi;
+                if (g.kind == 2 && lo > 0) lo_h = d_halo_r1_lo;
+            }
+            launch_time_transform(stream, yb, yb, g.kind, g.n, g.nx, lo_h, hi_h);
+        }
+    }
+    if (!fused_row_masks) {
+        // y = P y + alpha (I - P) x on Dirichlet blocks (preconditioner.py:527-537)
+        if (nx0 == nx1) {
+            launch_mask_blocks(stream, d_y, d_y, d_x, d_mask_jobs, nb, nx0);
+        } else {
+            launch_mask_blocks(stream, d_y, d_y, d_x, d_mask_jobs, n0_loc, nx0);
+            launch_mask_blocks(stream, d_y + (int64_t)n0_loc * nx0, d_y + (int64_t)n0_loc * nx0,
+                               d_x + (int64_t)n0_loc * nx0, d_mask_jobs + n0_loc, n1_loc, nx1);
+        }
+    }
+    if (any_const_ns) {
+        // y -= mean(y); y += alpha * mean(x)  (preconditioner.py:137-152)
+        for (int var = 0; var < 2; ++var) {
+            const int nloc = var == 0 ? n0_loc : n1_loc;
+            const int64_t nxv = var == 0 ? nx0 : nx1;
+            for (int il = 0; il < nloc; ++il) {
+                const int g = var == 0 ? global_row(0, il) : n0 + global_row(1, il);
+                if (nullspaces[g].kind != 2) continue;
+                double *yb = d_y + local_offset(var, il);
+                const double *xb = d_x + local_offset(var, il);
+                launch_block_sums(stream, yb, d_sums, 1, nxv, nullptr);
+                launch_block_shift(stream, yb, d_sums, -1.0 / (double)nxv, 1, nxv);
+                launch_block_sums(stream, xb, d_sums, 1, nxv, nullptr);
+                launch_block_shift(stream, yb, d_sums, nullspaces[g].alpha / (double)nxv, 1, nxv);
+            }
+        }
+    }
+}
+
+}  // namespace kkt

@@ -1,0 +1,161 @@
+"""Launcher-side plumbing for time-sharded systems: one process per GPU.
+
+The data path (halo hand-offs, Krylov all-reduces) lives in ``libkkt.so``
+(``csrc/comm.cpp``): RCCL over xGMI in production, or caller-provided host callbacks.
+This module only bootstraps a transport for a ``MultiBlockSystem``:
+
+* ``RcclComm``    -- production.  Rank 0 draws an ``ncclUniqueId`` and hands it to the
+                    other ranks of the node through a file under ``/tmp`` keyed by the
+                    launcher's pid and ``MASTER_PORT`` (all ranks of one node share both).
+* ``CallbackComm``-- host-staged transport over any pair of Python functions
+                    (``multiprocessing`` pipes in the tests, ``torch.distributed``/gloo).
+
+No PyTorch is imported here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+
+import numpy as np
+
+from . import _lib
+
+__all__ = ["RcclComm", "CallbackComm", "PipeTransport", "make_comm", "shard_range"]
+
+
+def shard_range(m, rank, world):
+    lo, hi = C.c_int(), C.c_int()
+    rc = _lib.load().kkt_shard_range(m, rank, world, C.byref(lo), C.byref(hi))
+    if rc != 0:
+        raise ValueError("bad shard arguments")
+    return lo.value, hi.value
+
+
+class _CommBase:
+    def __init__(self, rank, world):
+        self.rank, self.world = int(rank), int(world)
+        self._n_attached = 0
+
+    def attach(self, system):
+        raise NotImplementedError
+
+
+class RcclComm(_CommBase):
+    """RCCL transport; ``attach`` creates one communicator per system."""
+
+    def __init__(self, rank, world, rendezvous_dir=None, timeout=300.0):
+        super().__init__(rank, world)
+        if rendezvous_dir is None:
+            key = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+            rendezvous_dir = os.path.join("/tmp", f"kkt_rdv_{key}")
+        self._dir = rendezvous_dir
+        self._timeout = timeout
+        os.makedirs(self._dir, exist_ok=True)
+
+    def _exchange_id(self, lib):
+        path = os.path.join(self._dir, f"uid_{self._n_attached}")
+        if self.rank == 0:
+            buf = C.create_string_buffer(128)
+            rc = lib.kkt_comm_unique_id(buf)
+            if rc != 0:
+                raise _lib.KktError(rc, lib.kkt_last_error(None).decode())
+            tmp = path + f".tmp{os.getpid()}"
+            with open(tmp, "wb") as f:
+                f.write(buf.raw)
+            os.replace(tmp, path)          # atomic: readers see all 128 bytes or nothing
+            return buf.raw
+        t0 = time.time()
+        while True:
+            try:
+                with open(path, "rb") as f:
+                    raw = f.read()
+                if len(raw) == 128:
+                    return raw
+            except FileNotFoundError:
+                pass
+            if time.time() - t0 > self._timeout:
+                raise TimeoutError(f"no RCCL unique id at {path}")
+            time.sleep(0.01)
+
+    def attach(self, system):
+        lib = system._lib
+        raw = self._exchange_id(lib)
+        self._n_attached += 1
+        buf = C.create_string_buffer(raw, 128)
+        system._ck(lib.kkt_comm_init_rccl(system.handle, buf))
+
+
+class CallbackComm(_CommBase):
+    """Host-staged transport.  ``allreduce(buf: ndarray, op)`` reduces in place over ranks
+    (op 0 = sum, 1 = max); ``sendrecv(send, dst, n_recv, src) -> ndarray | None``."""
+
+    def __init__(self, rank, world, allreduce, sendrecv):
+        super().__init__(rank, world)
+        self._ar, self._sr = allreduce, sendrecv
+        self._keep = []
+
+    def attach(self, system):
+        ar, sr = self._ar, self._sr
+
+        def c_allreduce(user, buf, n, op):
+            try:
+                a = np.ctypeslib.as_array(buf, shape=(n,))
+                ar(a, op)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def c_sendrecv(user, send, n_send, dst, recv, n_recv, src):
+            try:
+                s = np.ctypeslib.as_array(send, shape=(n_send,)) if n_send > 0 else None
+                r = sr(s, dst, int(n_recv), src)
+                if n_recv > 0:
+                    np.ctypeslib.as_array(recv, shape=(n_recv,))[:] = r
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        f1, f2 = _lib.ALLREDUCE_FN(c_allreduce), _lib.SENDRECV_FN(c_sendrecv)
+        self._keep += [f1, f2]
+        system._ck(system._lib.kkt_comm_init_callbacks(system.handle, f1, f2, None))
+        self._n_attached += 1
+
+
+class PipeTransport:
+    """allreduce / sendrecv over ``multiprocessing`` connections (tests, few ranks).
+
+    ``conns[r]`` is a duplex connection to rank r (None for the own rank).  Sums are
+    formed in rank order on every rank, so all ranks hold bitwise-identical results.
+    """
+
+    def __init__(self, rank, world, conns):
+        self.rank, self.world, self.conns = rank, world, conns
+
+    def allreduce(self, buf, op):
+        mine = np.array(buf, copy=True)
+        for r in range(self.world):
+            if r != self.rank:
+                self.conns[r].send(mine)
+        parts = [mine if r == self.rank else self.conns[r].recv() for r in range(self.world)]
+        out = parts[0].copy()
+        for q in parts[1:]:
+            out = out + q if op == 0 else np.maximum(out, q)
+        buf[:] = out
+
+    def sendrecv(self, send, dst, n_recv, src):
+        if dst is not None and dst >= 0 and send is not None:
+            self.conns[dst].send(np.array(send, copy=True))
+        if src is not None and src >= 0 and n_recv > 0:
+            return self.conns[src].recv()
+        return None
+
+
+def make_comm(rank, world, local_rank=0):
+    """Production transport for ``bench.py`` under ``torch.distributed.run``."""
+    return RcclComm(rank, world)

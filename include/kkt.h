@@ -1,0 +1,233 @@
+/*
+ * libkkt -- MI355X-native all-at-once KKT solver: C-ABI drop-in boundary.
+ *
+ * The reference (sleveque/control) has no native code and no FFI; its boundary for this
+ * path is the Python class preconditioner/preconditioner.py:216 `MultiBlockSystem` and
+ * its method `.solve()` (preconditioner.py:337-786).  Every entry point below cites the
+ * reference lines whose work it takes over.  The Python mirror of that class
+ * (control_amd/multiblock.py) binds these symbols with ctypes; INTEGRATION.md shows the
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ types, no exceptions cross the boundary
+ *   - every function returns KKT_OK (0) or a negative KKT_ERR_* code; the message is
+ *     available from kkt_last_error()
+ *   - host arrays are caller-owned; the library copies during the call and never keeps
+ *     a host pointer after returning (pc callback excepted, see kkt_set_pc_callback)
+ *   - a handle is bound to one GPU and is not thread-safe
+ *   - vectors are fp64; the flat KKT vector is the n_blocks_00 blocks of variable 0
+ *     followed by the n_blocks_11 blocks of variable 1, block k at a contiguous offset
+ *     (preconditioner.py:286-287)
+ */
+#ifndef KKT_H
+#define KKT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kkt_system *kkt_handle;
+
+enum {
+    KKT_OK = 0,
+    KKT_ERR_ARG = -1,       /* bad argument / call order */
+    KKT_ERR_HIP = -2,       /* HIP runtime error */
+    KKT_ERR_STATE = -3,     /* object not in the state the call needs */
+    KKT_ERR_CALLBACK = -4,  /* a host preconditioner callback reported failure */
+    KKT_ERR_COMM = -5       /* multi-GPU transport error */
+};
+
+/* quadrants of the 2x2 block system (preconditioner.py:303) */
+enum { KKT_Q00 = 0, KKT_Q01 = 1, KKT_Q10 = 2, KKT_Q11 = 3 };
+
+/* Krylov methods (`solver_parameters["linear_solver"]`, preconditioner.py:733) */
+enum { KKT_KSP_GMRES = 0, KKT_KSP_FGMRES = 1 };
+/* `solver_parameters["pc_side"]` (preconditioner.py:735-736); DEFAULT = the method's own */
+enum { KKT_PC_SIDE_DEFAULT = -1, KKT_PC_LEFT = 0, KKT_PC_RIGHT = 1 };
+
+/* PETSc KSPConvergedReason values the reference tests against (preconditioner.py:769) */
+enum {
+    KKT_CONVERGED_RTOL = 2,
+    KKT_CONVERGED_ATOL = 3,
+    KKT_CONVERGED_HAPPY_BREAKDOWN = 5,
+    KKT_DIVERGED_ITS = -3,
+    KKT_DIVERGED_DTOL = -4,
+    KKT_DIVERGED_BREAKDOWN = -5,
+    KKT_DIVERGED_NANORINF = -9
+};
+
+/* ------------------------------------------------------------------ life cycle */
+
+/* One system on GPU `device_id`.  Replaces the MultiBlockSystem object
+ * (preconditioner.py:216-335). */
+int kkt_create(kkt_handle *out, int device_id);
+int kkt_destroy(kkt_handle h);
+/* Message of the last failing call on `h` (or of the last failing kkt_create if NULL). */
+const char *kkt_last_error(kkt_handle h);
+
+/* ------------------------------------------------------------------ definition */
+
+/* Block counts and spatial sizes (preconditioner.py:217-222, 276-302).
+ * sub_n_blocks_* = -1 means None.  Must precede every other definition call. */
+int kkt_set_layout(kkt_handle h, int n_blocks_00, int n_blocks_11,
+                   int64_t nx0, int64_t nx1, int CN,
+                   int sub_n_blocks_00_0, int sub_n_blocks_11_0);
+
+/* Time sharding (new functionality): this handle owns block rows
+ * [lo, hi) of BOTH variables, where [lo, hi) is rank's slice of n_blocks_00 ==
+ * n_blocks_11 rows split evenly over `world` ranks.  Vectors passed to every later call
+ * are the local shard [x0_lo..x0_hi-1, x1_lo..x1_hi-1].  Only blocks of owned rows may be
+ * added.  Omit for a single GPU. */
+int kkt_set_shard(kkt_handle h, int rank, int world);
+/* Row range owned by `rank` of `world` for `m` block rows (pure host arithmetic). */
+int kkt_shard_range(int m, int rank, int world, int *lo, int *hi);
+
+/* One assembled block A_ij of a quadrant as CSR (replaces `assemble(block_ij)`,
+ * preconditioner.py:305-328; the adapter feeds `petscmat.getValuesCSR()`).
+ * Column indices must be sorted within a row.  Blocks with the same share_id >= 0
+ * share one copy of the values on the device (time-invariant operators, "mode S");
+ * share_id < 0 gives the block its own copy ("mode G", what the reference stores).
+ * Blocks with identical sparsity structure always share the index arrays. */
+int kkt_add_block(kkt_handle h, int quadrant, int i, int j,
+                  int64_t nrows, int64_t ncols,
+                  const int32_t *indptr, const int32_t *indices,
+                  const double *values, int64_t share_id);
+/* New values on the stored structure of a block (re-linearisation in a Picard loop,
+ * control.py:3377-3590); valid after kkt_finalize. */
+int kkt_update_block_values(kkt_handle h, int quadrant, int i, int j,
+                            const double *values);
+
+/* DirichletBCNullspace(bcs, alpha) on flat block k (k < n_blocks_00: variable 0,
+ * otherwise variable 1): preconditioner.py:158-197. */
+int kkt_set_bc(kkt_handle h, int block_k, int64_t n_idx, const int32_t *idx,
+               double alpha);
+/* ConstantNullspace(alpha) on flat block k: preconditioner.py:133-155. */
+int kkt_set_const_nullspace(kkt_handle h, int block_k, double alpha);
+
+/* Freeze the definition and build the device data (HBM layout: DESIGN.md). */
+int kkt_finalize(kkt_handle h);
+
+/* ------------------------------------------------------------- preconditioner */
+
+enum { KKT_PC_STATIONARY = 0, KKT_PC_INSTATIONARY_BE = 1, KKT_PC_INSTATIONARY_CN = 2 };
+
+/* Built-in block Schur-complement preconditioner: the closures built by
+ * Control.Stationary.construct_pc (control.py:351-450) and
+ * Control.Instationary.construct_pc (control.py:1943-2440; CN 1995-2189, BE 2191-2438).
+ * It reads block_10 / block_01 from the blocks already added.  Mass solves are
+ * `mass_its` Jacobi-Chebyshev steps on [mass_emin, mass_emax] (control.py:1967-1982;
+ * mass_its == 0: one Jacobi application, control.py:1984-1991).  The hypre sub-solves of
+ * the reference are replaced by `schur_its` Jacobi-Chebyshev steps on
+ * [schur_emin, schur_emax] (BASELINE.json north_star). */
+typedef struct kkt_pc_desc {
+    int kind;            /* KKT_PC_* */
+    int n_t;             /* time levels (ignored for STATIONARY) */
+    double tau;          /* time step (ignored for STATIONARY) */
+    double beta;         /* regularisation parameter */
+    double epsilon;      /* BE final-time scaling, control.py:2836 (1e-3) */
+    int64_t nx;          /* spatial dofs of the mass matrix */
+    const int32_t *m_indptr;   /* mass matrix `self._M_v` as CSR */
+    const int32_t *m_indices;
+    const double *m_values;
+    int64_t n_bc;        /* homogeneous Dirichlet dofs (bcs_v = bcs_zeta) */
+    const int32_t *bc_idx;
+    int mass_its;
+    double mass_emin, mass_emax;
+    int schur_its;
+    double schur_emin, schur_emax;
+} kkt_pc_desc;
+
+int kkt_set_pc_schur(kkt_handle h, const kkt_pc_desc *desc);
+
+/* Arbitrary user `pc_fn(u_0, u_1, b_0, b_1)` (preconditioner.py:337-345, 623-627) on host
+ * arrays: slow path kept for API parity (`P=` of every *_solve, control.py:3257-3258).
+ * The library downloads b, calls `fn`, uploads u.  Non-zero return -> the solve fails
+ * with KKT_ERR_CALLBACK ("Error encountered in PETSc solve", preconditioner.py:771-772). */
+typedef int (*kkt_pc_callback)(void *user, const double *b_0, const double *b_1,
+                               double *u_0, double *u_1);
+int kkt_set_pc_callback(kkt_handle h, kkt_pc_callback fn, void *user);
+/* Default pc_fn: u = b (preconditioner.py:342-345). */
+int kkt_set_pc_identity(kkt_handle h);
+
+/* ---------------------------------------------------------------------- solve */
+
+/* KSP options (preconditioner.py:732-748): type, side, GMRES restart, tolerances.
+ * divtol <= 0 selects PETSc's default 1e4. */
+int kkt_set_krylov(kkt_handle h, int type, int pc_side, int restart,
+                   double rtol, double atol, double divtol, int max_it);
+
+/* y = A x: MultiBlockSystemMatrix.mult (preconditioner.py:375-543), host arrays. */
+int kkt_apply(kkt_handle h, const double *x, double *y);
+/* y = P^-1 x: Preconditioner.apply (preconditioner.py:562-656), host arrays. */
+int kkt_pc_apply(kkt_handle h, const double *x, double *y);
+/* The whole of MultiBlockSystem.solve after the matrices exist (preconditioner.py:
+ * 658-766): corrected initial guess and right-hand side, Krylov loop, corrected
+ * solution.  `u` holds the initial guess on entry and the solution on return.
+ * hist (may be NULL) receives the monitored residual norms, iteration 0 first. */
+int kkt_solve(kkt_handle h, const double *b, double *u,
+              int *its, int *reason, double *rnorm,
+              double *hist, int hist_cap, int *hist_len);
+
+/* ---------------------------------------------------- device-resident variants */
+
+/* Vectors that stay in HBM between calls (benchmarks; callers with resident data). */
+int64_t kkt_local_size(kkt_handle h);             /* doubles in one local KKT vector */
+int kkt_vec_alloc(kkt_handle h, double **d_vec);
+int kkt_vec_free(kkt_handle h, double *d_vec);
+int kkt_vec_upload(kkt_handle h, double *d_vec, const double *host);
+int kkt_vec_download(kkt_handle h, const double *d_vec, double *host);
+int kkt_apply_device(kkt_handle h, const double *d_x, double *d_y);
+int kkt_pc_apply_device(kkt_handle h, const double *d_x, double *d_y);
+int kkt_solve_device(kkt_handle h, const double *d_b, double *d_u,
+                     int *its, int *reason, double *rnorm,
+                     double *hist, int hist_cap, int *hist_len);
+int kkt_sync(kkt_handle h);
+
+/* `reps` back-to-back kkt_apply_device / kkt_pc_apply_device launches timed with HIP
+ * events on the library's own stream; *ms = total elapsed milliseconds. */
+int kkt_time_apply(kkt_handle h, const double *d_x, double *d_y, int reps, float *ms);
+int kkt_time_pc_apply(kkt_handle h, const double *d_x, double *d_y, int reps, float *ms);
+
+/* Byte accounting of the stored operator ("algorithmic bytes"). */
+typedef struct kkt_info {
+    int64_t n_local;            /* local KKT vector length */
+    int64_t n_blocks_stored;    /* (i,j) blocks held by this handle */
+    int64_t n_value_arrays;     /* distinct value arrays (== blocks in mode G) */
+    int64_t n_patterns;         /* distinct sparsity structures */
+    int64_t nnz_blocks;         /* sum of nnz over stored blocks */
+    int64_t rows_blocks;        /* sum of rows over stored blocks */
+    int64_t bytes_algorithmic;  /* sum_unique[12 nnz + 4(rows+1)] + 16 N */
+    int64_t bytes_device_values;/* padded value bytes actually resident */
+    int64_t bytes_device_index; /* padded index bytes actually resident */
+    double last_solve_ms;       /* wall time of the last kkt_solve* Krylov loop */
+    int64_t last_pc_applies;    /* preconditioner applications in the last solve */
+    int64_t last_op_applies;    /* operator applications in the last solve */
+} kkt_info;
+int kkt_get_info(kkt_handle h, kkt_info *info);
+
+/* ------------------------------------------------------------------ multi-GPU */
+
+/* Transport for time-sharded handles.  RCCL: `unique_id` is the 128-byte ncclUniqueId
+ * from kkt_comm_unique_id() on rank 0, distributed by the launcher. */
+int kkt_comm_unique_id(void *id_out_128);
+int kkt_comm_init_rccl(kkt_handle h, const void *unique_id_128);
+/* Host-staged transport through caller functions (tests; any launcher without RCCL).
+ * allreduce: in-place reduction over ranks of n doubles, op = KKT_OP_SUM or KKT_OP_MAX;
+ * sendrecv: send `n_send` doubles to `dst` (or -1: nothing) and receive `n_recv` from
+ * `src` (or -1).  Return 0 on success. */
+enum { KKT_OP_SUM = 0, KKT_OP_MAX = 1 };
+typedef int (*kkt_allreduce_fn)(void *user, double *buf, int n, int op);
+typedef int (*kkt_sendrecv_fn)(void *user, const double *send, int64_t n_send, int dst,
+                               double *recv, int64_t n_recv, int src);
+int kkt_comm_init_callbacks(kkt_handle h, kkt_allreduce_fn ar, kkt_sendrecv_fn sr,
+                            void *user);
+/* Barrier and max over ranks of a scalar (timing bracket of bench.py). */
+int kkt_comm_barrier(kkt_handle h);
+int kkt_comm_max(kkt_handle h, double *value_inout);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KKT_H */

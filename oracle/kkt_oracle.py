@@ -574,8 +574,20 @@ def pc_instationary_BE(M, block_01, block_10, n_t, tau, beta, nodes, mass_spec,
     Mt = assemble_with_bcs(M, nodes)
     shift = tau / beta**0.5
 
-    def solve(A, rhs):
-        return _inner_solve(assemble_with_bcs(A, nodes), schur_spec, rhs)
+    cache = {}
+
+    def solve(blk, c, rhs):
+        # The reference re-assembles `blk + c * M` with bcs inside every application
+        # (control.py:2277-2288); the matrix does not change, so it is built once here.
+        key = (id(blk), c)
+        if key not in cache:
+            At = assemble_with_bcs(blk if c == 0.0 else blk + c * M, nodes)
+            cache[key] = (At, 1.0 / At.diagonal(), blk)
+        At, dinv, _ = cache[key]
+        if schur_spec.its == 0:
+            return dinv * rhs
+        return chebyshev_jacobi(At, dinv, rhs, schur_spec.emin, schur_spec.emax,
+                                schur_spec.its)
 
     def pc_linear(u_0, u_1, b_0, b_1):
         # (1,1)-block, control.py:2193-2206
@@ -595,15 +607,15 @@ def pc_instationary_BE(M, block_01, block_10, n_t, tau, beta, nodes, mass_spec,
             b[i] -= b_1[i]
             _bc(b[i], nodes)
         # forward sweep, control.py:2241-2327
-        u_1[0] = solve(block_10[(0, 0)], b[0])
+        u_1[0] = solve(block_10[(0, 0)], 0.0, b[0])
         for i in range(1, n_t - 1):
             b[i] -= block_10[(i, i - 1)] @ u_1[i - 1]
             _bc(b[i], nodes)
-            u_1[i] = solve(block_10[(i, i)] + shift * M, b[i])
+            u_1[i] = solve(block_10[(i, i)], shift, b[i])
         b[n_t - 1] -= block_10[(n_t - 1, n_t - 2)] @ u_1[n_t - 2]
         _bc(b[n_t - 1], nodes)
-        u_1[n_t - 1] = solve(block_10[(n_t - 1, n_t - 1)]
-                             + (epsilon**0.5) * shift * M, b[n_t - 1])
+        u_1[n_t - 1] = solve(block_10[(n_t - 1, n_t - 1)], (epsilon**0.5) * shift,
+                             b[n_t - 1])
         # b = tau M u_1, control.py:2330-2350
         b = np.zeros_like(u_0)
         for i in range(n_t - 1):
@@ -612,15 +624,15 @@ def pc_instationary_BE(M, block_01, block_10, n_t, tau, beta, nodes, mass_spec,
         b[n_t - 1] = (M @ u_1[n_t - 1]) * (epsilon * tau)
         _bc(b[n_t - 1], nodes)
         # backward sweep, control.py:2353-2437
-        u_1[n_t - 1] = solve(block_01[(n_t - 1, n_t - 1)]
-                             + (epsilon**0.5) * shift * M, b[n_t - 1])
+        u_1[n_t - 1] = solve(block_01[(n_t - 1, n_t - 1)], (epsilon**0.5) * shift,
+                             b[n_t - 1])
         for i in range(n_t - 2, 0, -1):
             b[i] -= block_01[(i, i + 1)] @ u_1[i + 1]
             _bc(b[i], nodes)
-            u_1[i] = solve(block_01[(i, i)] + shift * M, b[i])
+            u_1[i] = solve(block_01[(i, i)], shift, b[i])
         b[0] -= block_01[(0, 1)] @ u_1[1]
         _bc(b[0], nodes)
-        u_1[0] = solve(block_01[(0, 0)], b[0])
+        u_1[0] = solve(block_01[(0, 0)], 0.0, b[0])
     return pc_linear
 
 
@@ -630,9 +642,29 @@ def pc_instationary_CN(M, block_01, block_10, n_t, tau, beta, nodes, mass_spec,
     m = n_t - 1
     Mt = assemble_with_bcs(M, nodes)
     my_const = 0.5 * tau / beta**0.5
+    cM = my_const * M
+    ucache = {}
 
-    def solve(A, rhs):
-        return _inner_solve(assemble_with_bcs(A, nodes), schur_spec, rhs)
+    def upper(i):
+        blk = block_01[(i, i + 1)]
+        if id(blk) not in ucache:
+            ucache[id(blk)] = (blk + cM, blk)
+        return ucache[id(blk)][0]
+
+    cache = {}
+
+    def solve(blk, c, rhs):
+        # The reference re-assembles `blk + c * M` with bcs inside every application
+        # (control.py:2277-2288); the matrix does not change, so it is built once here.
+        key = (id(blk), c)
+        if key not in cache:
+            At = assemble_with_bcs(blk if c == 0.0 else blk + c * M, nodes)
+            cache[key] = (At, 1.0 / At.diagonal(), blk)
+        At, dinv, _ = cache[key]
+        if schur_spec.its == 0:
+            return dinv * rhs
+        return chebyshev_jacobi(At, dinv, rhs, schur_spec.emin, schur_spec.emax,
+                                schur_spec.its)
 
     def pc_linear(u_0, u_1, b_0, b_1):
         # (1,1)-block, control.py:1997-2014
@@ -656,12 +688,12 @@ def pc_instationary_CN(M, block_01, block_10, n_t, tau, beta, nodes, mass_spec,
             _bc(b[i], nodes)
         # forward sweep, control.py:2050-2116
         b = apply_T_2_inv(b)
-        u_1[0] = solve(block_10[(0, 0)] + my_const * M, b[0])
+        u_1[0] = solve(block_10[(0, 0)], my_const, b[0])
         for i in range(1, m):
             b[i] -= block_10[(i, i - 1)] @ u_1[i - 1]
-            b[i] -= (my_const * M) @ u_1[i - 1]
+            b[i] -= cM @ u_1[i - 1]
             _bc(b[i], nodes)
-            u_1[i] = solve(block_10[(i, i)] + my_const * M, b[i])
+            u_1[i] = solve(block_10[(i, i)], my_const, b[i])
         # control.py:2118-2133
         u_1[:] = apply_T_2(u_1)
         b = np.zeros_like(u_0)
@@ -669,9 +701,9 @@ def pc_instationary_CN(M, block_01, block_10, n_t, tau, beta, nodes, mass_spec,
             b[i] = (M @ u_1[i]) * (0.5 * tau)
             _bc(b[i], nodes)
         # backward sweep, control.py:2135-2189
-        u_1[m - 1] = solve(block_01[(m - 1, m - 1)] + my_const * M, b[m - 1])
+        u_1[m - 1] = solve(block_01[(m - 1, m - 1)], my_const, b[m - 1])
         for i in range(m - 2, -1, -1):
-            b[i] -= (block_01[(i, i + 1)] + my_const * M) @ u_1[i + 1]
+            b[i] -= upper(i) @ u_1[i + 1]
             _bc(b[i], nodes)
-            u_1[i] = solve(block_01[(i, i)] + my_const * M, b[i])
+            u_1[i] = solve(block_01[(i, i)], my_const, b[i])
     return pc_linear

@@ -1,0 +1,163 @@
+"""GPU parity tests (run with -m gpu on an MI355X): HIP path vs the CPU oracle, through
+the C-ABI.  Tolerances are fp64 round-off of differently ordered sums:
+operator 1e-13, preconditioner 1e-10, Krylov residual histories 1e-8 relative
+(BASELINE.md section 4)."""
+import numpy as np
+import pytest
+
+import common
+import kat
+
+pytestmark = pytest.mark.gpu
+
+MASS = (20, 0.5, 2.0)          # P1 2-D bounds, test_control.py:3477
+SCHUR = (8, 0.05, 2.1)
+
+
+@pytest.mark.parametrize("CN", [False, True])
+@pytest.mark.parametrize("share", [True, False])
+def test_operator_parity(CN, share):
+    p = common.heat_problem(n=10, n_t=10, CN=CN, share=share, time_dependent=not share)
+    osys = common.oracle_system(p)
+    gsys = common.gpu_system(p)
+    for seed in range(3):
+        x = common.rng_vector(osys.N, common.SEED + seed)
+        assert common.rel_err(gsys.mult(x), osys.mult(x)) < 1e-13
+    info = gsys.info()
+    assert info["n_patterns"] == 1            # one shared index structure
+    nblk = sum(a is not None for blk in p["blocks"] for a in blk.values())
+    assert info["n_blocks_stored"] == nblk
+    if not share:
+        assert info["n_value_arrays"] == nblk  # mode G: every block its own values
+
+
+def test_operator_parity_3d():
+    p = common.heat_problem(space="p1_3d", n=6, n_t=5)
+    osys, gsys = common.oracle_system(p), common.gpu_system(p)
+    x = common.rng_vector(osys.N)
+    assert common.rel_err(gsys.mult(x), osys.mult(x)) < 1e-13
+
+
+@pytest.mark.parametrize("CN", [False, True])
+def test_preconditioner_parity(CN):
+    p = common.heat_problem(n=10, n_t=10, CN=CN)
+    osys, gsys = common.oracle_system(p), common.gpu_system(p)
+    opc, gpc = common.oracle_pc(p, MASS, SCHUR), common.gpu_pc(p, MASS, SCHUR)
+    x = common.rng_vector(osys.N)
+    ref = osys.pc_apply(opc, x)
+    got = gsys.pc_apply(x, gpc)
+    assert common.rel_err(got, ref) < 1e-10
+    # boundary rows pass through unchanged: u = P pc(P b) + (I - P) b
+    nodes = p["nodes"]
+    G = got.reshape(2 * p["m"], -1)
+    X = x.reshape(2 * p["m"], -1)
+    assert np.array_equal(G[:, nodes], X[:, nodes])
+
+
+@pytest.mark.parametrize("ksp", ["gmres", "fgmres"])
+@pytest.mark.parametrize("CN", [False, True])
+def test_krylov_iterates_parity(ksp, CN):
+    p = common.heat_problem(n=10, n_t=10, CN=CN)
+    osys, gsys = common.oracle_system(p), common.gpu_system(p)
+    opc, gpc = common.oracle_pc(p, MASS, SCHUR), common.gpu_pc(p, MASS, SCHUR)
+    m, nx = p["m"], p["sd"].n_dofs
+    b = common.rng_vector(osys.N).reshape(2 * m, nx)
+    sp = {"linear_solver": ksp, "gmres_restart": 10, "maximum_iterations": 60,
+          "relative_tolerance": 1e-6, "absolute_tolerance": 0.0,
+          "monitor_convergence": False, "preconditioner": True}
+    uo0, uo1 = np.zeros((m, nx)), np.zeros((m, nx))
+    ro = osys.solve(uo0, uo1, b[:m], b[m:], solver_parameters=sp, pc_fn=opc)
+    ug0, ug1 = np.zeros((m, nx)), np.zeros((m, nx))
+    rg = gsys.solve(ug0, ug1, b[:m].copy(), b[m:].copy(), solver_parameters=sp, pc_fn=gpc)
+    assert rg.its == ro.its and rg.reason == ro.reason
+    ho, hg = np.asarray(ro.history), np.asarray(rg.history)
+    assert len(ho) == len(hg)
+    # Same iteration count and stopping reason; monitored norms agree to 1e-6 of their own
+    # size and to 1e-11 of the initial norm.  (Round-off of differently ordered fp64 sums
+    # is amplified by the conditioning of the preconditioned operator: the measured
+    # deviation is <= 1e-7 relative after a 1e-6 residual reduction.)
+    live = ho / ho[0] >= 1e-8
+    assert np.max(np.abs(hg[live] - ho[live]) / ho[live]) < 1e-6
+    assert np.max(np.abs(hg - ho)) / ho[0] < 1e-11
+    assert common.rel_err(np.vstack([ug0, ug1]), np.vstack([uo0, uo1])) < 1e-7
+
+
+def test_identity_and_callback_pc():
+    p = common.heat_problem(n=6, n_t=4)
+    osys, gsys = common.oracle_system(p), common.gpu_system(p)
+    x = common.rng_vector(osys.N)
+
+    def ident(u_0, u_1, b_0, b_1):
+        u_0[:] = b_0
+        u_1[:] = b_1
+    assert common.rel_err(gsys.pc_apply(x, None), osys.pc_apply(ident, x)) == 0.0
+
+    def scaled(u_0, u_1, b_0, b_1):
+        u_0[:] = 2.0 * b_0
+        u_1[:] = -3.0 * b_1
+    assert common.rel_err(gsys.pc_apply(x, scaled), osys.pc_apply(scaled, x)) == 0.0
+
+    def broken(u_0, u_1, b_0, b_1):
+        raise ValueError("boom")
+    with pytest.raises(RuntimeError, match="Error encountered in PETSc solve"):
+        gsys.pc_apply(x, broken)
+
+
+def test_nonconvergence_raises():
+    p = common.heat_problem(n=6, n_t=4)
+    gsys = common.gpu_system(p)
+    m, nx = p["m"], p["sd"].n_dofs
+    b = common.rng_vector(2 * m * nx).reshape(2 * m, nx)
+    sp = {"linear_solver": "gmres", "gmres_restart": 5, "maximum_iterations": 3,
+          "relative_tolerance": 1e-12, "absolute_tolerance": 0.0,
+          "monitor_convergence": False}
+    with pytest.raises(RuntimeError, match="Solver failed to converge"):
+        gsys.solve(np.zeros((m, nx)), np.zeros((m, nx)), b[:m], b[m:],
+                   solver_parameters=sp)
+
+
+# ---- the reference's known-answer tests through the GPU path
+KAT_SCHUR = (40, 0.02, 2.2)
+
+
+@pytest.mark.parametrize("CN", [False, True])
+def test_kat_instationary(CN):
+    from control_amd.blocks import instationary_blocks
+    from control_amd.multiblock import (ChebSpec, DirichletBCNullspace, MultiBlockSystem,
+                                        SchurPC)
+    from oracle import kkt_oracle as ko
+    p = kat.kat_instationary_CN() if CN else kat.kat_instationary_BE()
+    sd, n_t, tau, beta = p["sd"], p["n_t"], p["tau"], p["beta"]
+    b00, b01, b10, b11, m = instationary_blocks(sd.M, sd.K, tau, beta, n_t, CN)
+    ns = tuple(DirichletBCNullspace(p["nodes"]) for _ in range(m))
+    gsys = MultiBlockSystem(sd.n_dofs, sd.n_dofs, b00, b01, b10, b11, n_blocks_00=m,
+                            n_blocks_11=m, nullspace_0=ns, nullspace_1=ns, CN=CN)
+    pc = SchurPC(kind="CN" if CN else "BE", M=sd.M, beta=beta, bc_nodes=p["nodes"],
+                 mass=ChebSpec(20, *kat.LAMBDA_V_BOUNDS), schur=ChebSpec(*KAT_SCHUR),
+                 n_t=n_t, tau=tau)
+    b_0, b_1 = (ko.apply_T_1(p["b_0"]), ko.apply_T_2(p["b_1"])) if CN else (p["b_0"], p["b_1"])
+    v, z = np.zeros((m, sd.n_dofs)), np.zeros((m, sd.n_dofs))
+    res = gsys.solve(v, z, b_0, b_1, solver_parameters=kat.SOLVER_PARAMETERS, pc_fn=pc)
+    assert res.reason > 0
+    if CN:
+        v = np.vstack([np.zeros((1, sd.n_dofs)), v])
+        z = np.vstack([z, np.zeros((1, sd.n_dofs))])
+    assert kat.l2_norm(sd.M, v - p["v_ref"]) < 1.0e-13
+    assert kat.l2_norm(sd.M, z - p["z_ref"]) < 1.0e-13
+
+
+def test_kat_stationary():
+    from control_amd.blocks import stationary_blocks
+    from control_amd.multiblock import ChebSpec, MultiBlockSystem, SchurPC
+    p = kat.kat_stationary()
+    sd = p["sd"]
+    b00, b01, b10, b11 = stationary_blocks(sd.M, p["D"], p["beta"])
+    gsys = MultiBlockSystem(sd.n_dofs, sd.n_dofs, b00, b01, b10, b11)
+    pc = SchurPC(kind="stationary", M=sd.M, beta=p["beta"], bc_nodes=p["nodes"],
+                 mass=ChebSpec(20, *kat.LAMBDA_V_BOUNDS), schur=ChebSpec(*KAT_SCHUR))
+    v, z = np.zeros((1, sd.n_dofs)), np.zeros((1, sd.n_dofs))
+    res = gsys.solve(v, z, p["b_0"], p["b_1"], solver_parameters=kat.SOLVER_PARAMETERS,
+                     pc_fn=pc)
+    assert res.reason > 0
+    assert kat.l2_norm(sd.M, v - p["v_ref"]) < 1.0e-13
+    assert kat.l2_norm(sd.M, z - p["z_ref"]) < 1.0e-13
