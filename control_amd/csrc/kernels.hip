@@ -24,134 +24,269 @@ __device__ __forceinline__ const double *resolve(const VRef &r, const Bases &B) 
 // has width w_s = max row length in it and owns slots [slice_off[s], slice_off[s+1]).
 // Entry k of row (s*C + lane*R + q) sits at (slice_off[s] + k)*C + lane*R + q, so one
 // wave-instruction reads 64*R consecutive values (R=2: 16 B per lane, 1 KiB per wave --
-// the widest coalesced access) and each lane owns R consecutive rows.  Matrix values
-// are streamed once with non-temporal loads so they do not evict the index array and
-// the x windows, which are re-used across blocks, from the XCD's L2.
+// the widest coalesced access) and each lane owns R consecutive rows.
 //
 // One workgroup = 4 waves = 4 slices; blockIdx.y picks the RowOp (block row).  All RowOp
 // fields are wave-uniform and come in through scalar loads.
+//
+// NT = true (the KKT operator apply): matrix values are streamed once with non-temporal
+// loads so they do not evict the shared index array and the x windows from the XCD's L2.
+// NT = false (preconditioner steps): the same few MB of matrix are re-read by every
+// Chebyshev step of a sweep and should stay in L2.
+//
+// The per-row sum is term-major with one fma chain per row in CSR order (the order of
+// the reference's MatMultAdd sequence, preconditioner.py:406-432).  For slice widths up
+// to 16 the loop is fully unrolled at the exact width so that all value loads of a term,
+// then all of its x gathers, are in flight together: small launches (one 66k-row block in
+// the preconditioner sweeps) are latency-bound and this removes dependent round trips.
+
+template <int R, bool NT>
+__device__ __forceinline__ void load_vals(const double *__restrict__ p, double (&v)[R]) {
+    if constexpr (R == 2) {
+        d2 t;
+        if constexpr (NT)
+            t = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(p));
+        else
+            t = *reinterpret_cast<const d2 *>(p);
+        v[0] = t.x;
+        v[1] = t.y;
+    } else {
+        if constexpr (NT)
+            v[0] = __builtin_nontemporal_load(p);
+        else
+            v[0] = *p;
+    }
+}
+
 template <int R>
-__device__ __forceinline__ void rowops_body(const RowOp *__restrict__ ops,
-                                                     const Bases bases) {
-    const RowOp &op = ops[blockIdx.y];
-    const int wave = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63;
-    const int s = blockIdx.x * 4 + wave;
-    if (s >= op.nslices) return;
+__device__ __forceinline__ void load_cols(const int32_t *__restrict__ p, int (&c)[R]) {
+    if constexpr (R == 2) {
+        const i2 t = *reinterpret_cast<const i2 *>(p);
+        c[0] = t.x;
+        c[1] = t.y;
+    } else {
+        c[0] = *p;
+    }
+}
+
+template <int R, bool NT, int W>
+__device__ __forceinline__ void accumulate_exact(const RowOp &op, const Bases &bases,
+                                                 size_t base, double (&acc)[R]) {
     constexpr int C = 64 * R;
-    const int off0 = op.slice_off[s];
-    const int w = op.slice_off[s + 1] - off0;
-    const size_t base = (size_t)off0 * C + (size_t)lane * R;
+    constexpr int CH = 8;                       // slots per register chunk
+    constexpr int NCH = (W + CH - 1) / CH;
     const int32_t *__restrict__ colp = op.col + base;
-
-    double acc[R];
+    int c[W][R];
 #pragma unroll
-    for (int q = 0; q < R; ++q) acc[q] = 0.0;
+    for (int k = 0; k < W; ++k) load_cols<R>(colp + (size_t)k * C, c[k]);
+    const int nterms = op.nterms;
+    double vn[CH][R];                           // values of the next (term, chunk)
+    {
+        const double *__restrict__ vp = op.t[0].vals + base;
+#pragma unroll
+        for (int k = 0; k < (W < CH ? W : CH); ++k) load_vals<R, NT>(vp + (size_t)k * C, vn[k]);
+    }
+    for (int t = 0; t < nterms; ++t) {
+        const double *__restrict__ x = resolve(op.t[t].x, bases);
+        const double *__restrict__ vcur = op.t[t].vals + base;
+        const double *__restrict__ vnext = (t + 1 < nterms) ? op.t[t + 1].vals + base : vcur;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int k0 = ch * CH;
+            const int n = (W - k0) < CH ? (W - k0) : CH;
+            double v[CH][R], xv[CH][R];
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+                if (k < n) {
+#pragma unroll
+                    for (int q = 0; q < R; ++q) {
+                        v[k][q] = vn[k][q];
+                        xv[k][q] = x[c[k0 + k][q]];
+                    }
+                }
+            // next chunk's (or next term's first chunk's) values go in flight now
+            if (ch + 1 < NCH) {
+                const int k1 = k0 + CH;
+                const int n1 = (W - k1) < CH ? (W - k1) : CH;
+#pragma unroll
+                for (int k = 0; k < CH; ++k)
+                    if (k < n1) load_vals<R, NT>(vcur + (size_t)(k1 + k) * C, vn[k]);
+            } else if (t + 1 < nterms) {
+#pragma unroll
+                for (int k = 0; k < (W < CH ? W : CH); ++k)
+                    load_vals<R, NT>(vnext + (size_t)k * C, vn[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+                if (k < n) {
+#pragma unroll
+                    for (int q = 0; q < R; ++q) acc[q] = __builtin_fma(v[k][q], xv[k][q], acc[q]);
+                }
+        }
+    }
+}
 
+template <int R, bool NT>
+__device__ __forceinline__ void accumulate_generic(const RowOp &op, const Bases &bases,
+                                                   size_t base, int w, double (&acc)[R]) {
+    constexpr int C = 64 * R;
+    const int32_t *__restrict__ colp = op.col + base;
     const int nterms = op.nterms;
     for (int t = 0; t < nterms; ++t) {
         const double *__restrict__ vp = op.t[t].vals + base;
         const double *__restrict__ x = resolve(op.t[t].x, bases);
 #pragma unroll 4
         for (int k = 0; k < w; ++k) {
-            if constexpr (R == 2) {
-                const i2 c = *reinterpret_cast<const i2 *>(colp + (size_t)k * C);
-                const d2 v = __builtin_nontemporal_load(
-                    reinterpret_cast<const d2 *>(vp + (size_t)k * C));
-                acc[0] = __builtin_fma(v.x, x[c.x], acc[0]);
-                acc[1] = __builtin_fma(v.y, x[c.y], acc[1]);
-            } else {
-                const int c = colp[(size_t)k * C];
-                const double v = __builtin_nontemporal_load(vp + (size_t)k * C);
-                acc[0] = __builtin_fma(v, x[c], acc[0]);
-            }
+            int c[R];
+            double v[R];
+            load_cols<R>(colp + (size_t)k * C, c);
+            load_vals<R, NT>(vp + (size_t)k * C, v);
+#pragma unroll
+            for (int q = 0; q < R; ++q) acc[q] = __builtin_fma(v[q], x[c[q]], acc[q]);
         }
     }
+}
 
+// WFIX > 0: the launcher knows every slice of every RowOp in the launch has width WFIX
+// (structured meshes: 7 for 2-D P1, 15 for 3-D P1) and picks the kernel unrolled for it.
+template <int R, bool NT, int WFIX>
+__device__ __forceinline__ void rowops_body(const RowOp *__restrict__ ops, const Bases bases) {
+    const RowOp &op = ops[blockIdx.y];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + wave;
+    if (s >= op.nslices) return;
+    constexpr int C = 64 * R;
+    int off0, w;
+    if constexpr (WFIX > 0) {
+        w = WFIX;
+        off0 = s * WFIX;
+    } else if (op.uniform_w >= 0) {   // same width everywhere: no slice_off round trip
+        w = op.uniform_w;
+        off0 = s * w;
+    } else {
+        off0 = op.slice_off[s];
+        w = op.slice_off[s + 1] - off0;
+    }
+    const size_t base = (size_t)off0 * C + (size_t)lane * R;
     const int r0 = s * C + lane * R;
+    const int nrows = op.nrows;
+
+    // epilogue operands first: their latency overlaps the matrix stream
+    double e0[R], e1[R], e2[R], e3[R];
+    bool masked[R];
+    const bool lin = op.mode == EPI_LIN;
+    const double *pa, *pb, *pc, *pd;
+    if (lin) {
+        pa = resolve(op.yin, bases);
+        pb = resolve(op.z, bases);
+        pc = resolve(op.mx, bases);
+        pd = nullptr;
+    } else {
+        pa = resolve(op.pkm1, bases);
+        pb = resolve(op.pk, bases);
+        pc = resolve(op.b, bases);
+        pd = op.dinv;
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int r = r0 + q;
+        const bool in = r < nrows;
+        masked[q] = in && op.rowmask != nullptr && op.rowmask[r] != 0;
+        e0[q] = (in && pa) ? pa[r] : 0.0;
+        e1[q] = (in && pb) ? pb[r] : 0.0;
+        e2[q] = (in && pc) ? pc[r] : 0.0;
+        e3[q] = (in && pd) ? pd[r] : 0.0;
+    }
+
+    double acc[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) acc[q] = 0.0;
+    if (op.nterms > 0) {
+        if constexpr (WFIX > 0)
+            accumulate_exact<R, NT, WFIX>(op, bases, base, acc);
+        else
+            accumulate_generic<R, NT>(op, bases, base, w, acc);
+    }
+
     double *__restrict__ y = const_cast<double *>(resolve(op.y, bases));
     double out[R];
-    if (op.mode == EPI_LIN) {
-        const double *yin = resolve(op.yin, bases);
-        const double *z = resolve(op.z, bases);
-        const double *mx = resolve(op.mx, bases);
 #pragma unroll
-        for (int q = 0; q < R; ++q) {
-            const int r = r0 + q;
-            out[q] = 0.0;
-            if (r < op.nrows) {
-                const bool masked = op.rowmask != nullptr && op.rowmask[r] != 0;
-                if (masked) {
-                    out[q] = mx ? op.malpha * mx[r] : 0.0;
-                } else {
-                    double v = op.ca * acc[q];
-                    if (yin) v += op.cy * yin[r];
-                    if (z) v += op.cz * z[r];
-                    out[q] = v;
-                }
+    for (int q = 0; q < R; ++q) {
+        if (lin) {
+            // y = ca*acc + cy*yin + cz*z; masked rows: malpha * mx (0 without mx)
+            if (masked[q]) {
+                out[q] = pc ? op.malpha * e2[q] : 0.0;
+            } else {
+                double v = op.ca * acc[q];
+                if (pa) v += op.cy * e0[q];
+                if (pb) v += op.cz * e1[q];
+                out[q] = v;
             }
-        }
-    } else {
-        const double *b = resolve(op.b, bases);
-        const double *pk = resolve(op.pk, bases);
-        const double *pkm1 = resolve(op.pkm1, bases);
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-            const int r = r0 + q;
-            out[q] = 0.0;
-            if (r < op.nrows) {
-                const bool masked = op.rowmask != nullptr && op.rowmask[r] != 0;
-                if (!masked) {
-                    // (1-w) p_{k-1} + w p_k + (scale w) D^-1 (b - A p_k): VecAXPBYPCZ order
-                    double v = pkm1 ? op.c1 * pkm1[r] : 0.0;
-                    if (pk) v += op.c2 * pk[r];
-                    v += op.c3 * (op.dinv[r] * (b[r] - acc[q]));
-                    out[q] = op.post2 * (op.post1 * v);
-                }
+        } else {
+            // (1-w) p_{k-1} + w p_k + (scale w) D^-1 (b - A p_k): VecAXPBYPCZ order; masked
+            // rows: the bc-assembled matrix on a bc-clean right-hand side gives exactly 0
+            if (masked[q]) {
+                out[q] = 0.0;
+            } else {
+                double v = pa ? op.c1 * e0[q] : 0.0;
+                if (pb) v += op.c2 * e1[q];
+                v += op.c3 * (e3[q] * (e2[q] - acc[q]));
+                out[q] = op.post2 * (op.post1 * v);
             }
         }
     }
     if constexpr (R == 2) {
-        if (r0 + 1 < op.nrows) {
+        if (r0 + 1 < nrows) {
             d2u o;
             o.x = out[0];
             o.y = out[1];
             *reinterpret_cast<d2u *>(y + r0) = o;
-        } else if (r0 < op.nrows) {
+        } else if (r0 < nrows) {
             y[r0] = out[0];
         }
     } else {
-        if (r0 < op.nrows) y[r0] = out[0];
+        if (r0 < nrows) y[r0] = out[0];
     }
 }
 
 // Two entry points over one body so that profiles separate the KKT operator apply (the
 // roofline kernel of bench.py) from the many small block-row steps of the preconditioner.
-template <int R>
+template <int R, int WFIX>
 __global__ __launch_bounds__(256) void kkt_spmv_rows(const RowOp *__restrict__ ops,
                                                      const Bases bases) {
-    rowops_body<R>(ops, bases);
+    rowops_body<R, true, WFIX>(ops, bases);
 }
-template <int R>
+template <int R, int WFIX>
 __global__ __launch_bounds__(256) void pc_rows(const RowOp *__restrict__ ops,
                                                const Bases bases) {
-    rowops_body<R>(ops, bases);
+    rowops_body<R, false, WFIX>(ops, bases);
+}
+
+template <int R, int WFIX>
+static void launch_one(hipStream_t s, dim3 grid, const RowOp *d_ops, const Bases &bases, int tag) {
+    if (tag == 0)
+        hipLaunchKernelGGL((kkt_spmv_rows<R, WFIX>), grid, dim3(256), 0, s, d_ops, bases);
+    else
+        hipLaunchKernelGGL((pc_rows<R, WFIX>), grid, dim3(256), 0, s, d_ops, bases);
 }
 
 void launch_rowops(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, int R,
-                   const Bases &bases, int tag) {
+                   const Bases &bases, int tag, int uniform_w) {
     if (nops <= 0 || max_slices <= 0) return;
     dim3 grid((max_slices + 3) / 4, nops);
-    if (tag == 0) {
-        if (R == 2)
-            hipLaunchKernelGGL(kkt_spmv_rows<2>, grid, dim3(256), 0, s, d_ops, bases);
-        else
-            hipLaunchKernelGGL(kkt_spmv_rows<1>, grid, dim3(256), 0, s, d_ops, bases);
-    } else {
-        if (R == 2)
-            hipLaunchKernelGGL(pc_rows<2>, grid, dim3(256), 0, s, d_ops, bases);
-        else
-            hipLaunchKernelGGL(pc_rows<1>, grid, dim3(256), 0, s, d_ops, bases);
+    if (R != 2) {
+        launch_one<1, 0>(s, grid, d_ops, bases, tag);
+        return;
+    }
+    switch (uniform_w) {
+#define KKT_W(n) case n: launch_one<2, n>(s, grid, d_ops, bases, tag); break;
+        KKT_W(1) KKT_W(2) KKT_W(3) KKT_W(4) KKT_W(5) KKT_W(6) KKT_W(7) KKT_W(8)
+        KKT_W(9) KKT_W(10) KKT_W(11) KKT_W(12) KKT_W(13) KKT_W(14) KKT_W(15) KKT_W(16)
+#undef KKT_W
+        default: launch_one<2, 0>(s, grid, d_ops, bases, tag); break;
     }
 }
 

@@ -34,6 +34,8 @@ struct RowOp {
     const int32_t *col;        // SELL column indices of the shared pattern
     const int32_t *slice_off;  // nslices + 1 offsets, in slots
     int32_t nrows, nslices, nterms, mode;
+    int32_t uniform_w;         // >= 0: every slice has this width (slice_off unused)
+    int32_t pad0_;
     SpmvTerm t[MAX_TERMS];
     VRef y;
     // EPI_LIN:  y = ca*acc + cy*yin + cz*z;  masked rows: y = malpha * mx[r] (0 if !mx)
@@ -50,7 +52,7 @@ struct RowOp {
 };
 
 void launch_rowops(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, int R,
-                   const Bases &bases, int tag);
+                   const Bases &bases, int tag, int uniform_w);
 
 // ---- value-array preparation
 void launch_csr_to_sell(hipStream_t s, const double *csr_vals, const int32_t *sell2csr,

@@ -152,6 +152,7 @@ void SchurPC::emit_lin(const std::vector<Lin> &ops) {
         RowOp op{};
         op.col = P.d_col;
         op.slice_off = l.terms.empty() ? zero_off_ : P.d_slice_off;
+        op.uniform_w = l.terms.empty() ? 0 : P.uniform_w;
         op.nrows = (int32_t)nx_;
         op.nslices = P.nslices;
         op.nterms = (int32_t)l.terms.size();
@@ -176,6 +177,7 @@ void SchurPC::emit_lin(const std::vector<Lin> &ops) {
     s.rows.nops = (int)r.size();
     s.rows.max_slices = P.nslices;
     s.rows.R = P.R;
+    s.rows.uniform_w = P.uniform_w;
     s.rows.d_ops = dev_upload(r.data(), r.size());
     steps_.push_back(s);
 }
@@ -187,6 +189,7 @@ void SchurPC::emit_cheb(const std::vector<Cheb> &ops) {
         RowOp op{};
         op.col = P.d_col;
         op.slice_off = c.vals ? P.d_slice_off : zero_off_;
+        op.uniform_w = c.vals ? P.uniform_w : 0;
         op.nrows = (int32_t)nx_;
         op.nslices = P.nslices;
         op.nterms = c.vals ? 1 : 0;
@@ -214,6 +217,7 @@ void SchurPC::emit_cheb(const std::vector<Cheb> &ops) {
     s.rows.nops = (int)r.size();
     s.rows.max_slices = P.nslices;
     s.rows.R = P.R;
+    s.rows.uniform_w = P.uniform_w;
     s.rows.d_ops = dev_upload(r.data(), r.size());
     steps_.push_back(s);
 }
@@ -423,7 +427,8 @@ void SchurPC::replay() {
     for (const PcStep &s : steps_) {
         switch (s.kind) {
             case PcStep::ROWS:
-                launch_rowops(st, s.rows.d_ops, s.rows.nops, s.rows.max_slices, s.rows.R, B, 1);
+                launch_rowops(st, s.rows.d_ops, s.rows.nops, s.rows.max_slices, s.rows.R, B, 1,
+                              s.rows.uniform_w);
                 break;
             case PcStep::TIME:
                 launch_time_transform(st, s.y, s.x, s.tkind, s.n, s.nx, nullptr, nullptr);

@@ -148,7 +148,21 @@ int System::find_or_add_pattern(int64_t nrows, int64_t ncols, const int32_t *ind
             w = std::max(w, indptr[r + 1] - indptr[r]);
         }
         P.max_width = std::max(P.max_width, w);
+        if (s == 0)
+            P.uniform_w = w;
+        else if (P.uniform_w != w)
+            P.uniform_w = -1;
         off[s + 1] = off[s] + w;
+    }
+    // Nearly uniform structures (structured meshes: only the slices that hold boundary
+    // rows are narrower) are padded to one width so that the fixed-width kernels apply;
+    // accepted when it costs at most 3 % more slots.
+    if (P.uniform_w < 0 && P.max_width >= 1 && P.max_width <= 16) {
+        const int64_t uni = (int64_t)P.max_width * P.nslices;
+        if ((uni - off[P.nslices]) * 100 <= 3 * (int64_t)off[P.nslices]) {
+            for (int s = 0; s <= P.nslices; ++s) off[s] = s * P.max_width;
+            P.uniform_w = P.max_width;
+        }
     }
     P.nslots = off[P.nslices];
     P.npadded = P.nslots * C;
@@ -390,6 +404,7 @@ void System::finalize() {
                     const Pattern &P = patterns[pat];
                     op.col = P.d_col;
                     op.slice_off = P.d_slice_off;
+                    op.uniform_w = P.uniform_w;
                     op.nslices = P.nslices;
                     R = P.R;
                     nslices = P.nslices;
@@ -420,6 +435,7 @@ void System::finalize() {
                     // slice_off of zeros: every slice has width 0
                     std::vector<int32_t> z(nslices + 1, 0);
                     op.slice_off = dev_upload(z.data(), z.size());
+                    op.uniform_w = 0;
                 }
                 const bool last = t0 >= terms.size();
                 if (last && fused_row_masks && rns.kind == 1) {
@@ -441,6 +457,14 @@ void System::finalize() {
         L.nops = (int)waves[w].size();
         L.max_slices = wave_slices[w];
         L.R = wave_R[w];
+        L.uniform_w = 0;
+        for (const RowOp &op : waves[w]) {
+            if (op.nterms == 0) continue;
+            if (L.uniform_w == 0)
+                L.uniform_w = op.uniform_w;
+            else if (L.uniform_w != op.uniform_w)
+                L.uniform_w = -1;
+        }
         L.d_ops = dev_upload(waves[w].data(), waves[w].size());
         apply_launches.push_back(L);
     }
@@ -535,7 +559,7 @@ void System::apply(const double *d_x, double *d_y) {
     if (sharded) comm_exchange_x_halos(*this, xin);
     Bases B{{xin, d_y, d_halo_x0_lo, d_halo_x1_hi}};
     for (const RowLaunch &L : apply_launches)
-        launch_rowops(stream, L.d_ops, L.nops, L.max_slices, L.R, B, 0);
+        launch_rowops(stream, L.d_ops, L.nops, L.max_slices, L.R, B, 0, L.uniform_w);
     if (CN) {
         if (sharded) comm_exchange_row_halos(*this, d_y);
         for (const TimeGroup &g : time_groups) {

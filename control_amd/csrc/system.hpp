@@ -44,6 +44,7 @@ struct Pattern {
     int64_t nslots = 0;     // sum of slice widths
     int64_t npadded = 0;    // nslots * 64 * R
     int max_width = 0;
+    int uniform_w = -1;     // >= 0 when every slice has this width
     uint64_t hash = 0;
     std::vector<int32_t> h_indptr, h_indices;   // kept to prove equality, not just hash
     int32_t *d_col = nullptr;
@@ -83,6 +84,7 @@ struct RowLaunch {
     int nops = 0;
     int max_slices = 0;
     int R = 2;
+    int uniform_w = -1;   // > 0: every op with terms in this launch has this slice width
 };
 
 struct TimeGroup {   // CN transform applied to a contiguous range of local blocks
