@@ -152,8 +152,7 @@ __device__ __forceinline__ void accumulate_generic(const RowOp &op, const Bases 
 // WFIX > 0: the launcher knows every slice of every RowOp in the launch has width WFIX
 // (structured meshes: 7 for 2-D P1, 15 for 3-D P1) and picks the kernel unrolled for it.
 template <int R, bool NT, int WFIX>
-__device__ __forceinline__ void rowops_body(const RowOp *__restrict__ ops, const Bases bases) {
-    const RowOp &op = ops[blockIdx.y];
+__device__ __forceinline__ void rowops_body(const RowOp &op, const Bases &bases) {
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     const int s = blockIdx.x * 4 + wave;
@@ -183,7 +182,7 @@ __device__ __forceinline__ void rowops_body(const RowOp *__restrict__ ops, const
         pa = resolve(op.yin, bases);
         pb = resolve(op.z, bases);
         pc = resolve(op.mx, bases);
-        pd = nullptr;
+        pd = op.y2.base >= 0 ? op.dinv : nullptr;
     } else {
         pa = resolve(op.pkm1, bases);
         pb = resolve(op.pk, bases);
@@ -212,9 +211,10 @@ __device__ __forceinline__ void rowops_body(const RowOp *__restrict__ ops, const
     }
 
     double *__restrict__ y = const_cast<double *>(resolve(op.y, bases));
-    double out[R];
+    double out[R], out2[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) {
+        out2[q] = 0.0;
         if (lin) {
             // y = ca*acc + cy*yin + cz*z; masked rows: malpha * mx (0 without mx)
             if (masked[q]) {
@@ -225,6 +225,9 @@ __device__ __forceinline__ void rowops_body(const RowOp *__restrict__ ops, const
                 if (pb) v += op.cz * e1[q];
                 out[q] = v;
             }
+            // optional second output: first Chebyshev step on the row just formed,
+            // y2 = c3 * D^-1 y  (p_1 = scale D^-1 b with b = y)
+            out2[q] = op.c3 * (e3[q] * out[q]);
         } else {
             // (1-w) p_{k-1} + w p_k + (scale w) D^-1 (b - A p_k): VecAXPBYPCZ order; masked
             // rows: the bc-assembled matrix on a bc-clean right-hand side gives exactly 0
@@ -250,6 +253,12 @@ __device__ __forceinline__ void rowops_body(const RowOp *__restrict__ ops, const
     } else {
         if (r0 < nrows) y[r0] = out[0];
     }
+    if (lin && op.y2.base >= 0) {
+        double *__restrict__ y2 = const_cast<double *>(resolve(op.y2, bases));
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+            if (r0 + q < nrows) y2[r0 + q] = out2[q];
+    }
 }
 
 // Two entry points over one body so that profiles separate the KKT operator apply (the
@@ -257,36 +266,46 @@ __device__ __forceinline__ void rowops_body(const RowOp *__restrict__ ops, const
 template <int R, int WFIX>
 __global__ __launch_bounds__(256) void kkt_spmv_rows(const RowOp *__restrict__ ops,
                                                      const Bases bases) {
-    rowops_body<R, true, WFIX>(ops, bases);
+    rowops_body<R, true, WFIX>(ops[blockIdx.y], bases);
 }
 template <int R, int WFIX>
 __global__ __launch_bounds__(256) void pc_rows(const RowOp *__restrict__ ops,
                                                const Bases bases) {
-    rowops_body<R, false, WFIX>(ops, bases);
+    rowops_body<R, false, WFIX>(ops[blockIdx.y], bases);
+}
+// One RowOp passed by value: the descriptor arrives with the kernel arguments instead of
+// through a dependent load -- one round trip less on the latency-bound sweep steps.
+template <int R, int WFIX>
+__global__ __launch_bounds__(256) void pc_row_step(const RowOp op, const Bases bases) {
+    rowops_body<R, false, WFIX>(op, bases);
 }
 
 template <int R, int WFIX>
-static void launch_one(hipStream_t s, dim3 grid, const RowOp *d_ops, const Bases &bases, int tag) {
-    if (tag == 0)
+static void launch_one(hipStream_t s, dim3 grid, const RowOp *d_ops, const Bases &bases, int tag,
+                       const RowOp *h_single) {
+    if (h_single && tag != 0)
+        hipLaunchKernelGGL((pc_row_step<R, WFIX>), grid, dim3(256), 0, s, *h_single, bases);
+    else if (tag == 0)
         hipLaunchKernelGGL((kkt_spmv_rows<R, WFIX>), grid, dim3(256), 0, s, d_ops, bases);
     else
         hipLaunchKernelGGL((pc_rows<R, WFIX>), grid, dim3(256), 0, s, d_ops, bases);
 }
 
 void launch_rowops(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, int R,
-                   const Bases &bases, int tag, int uniform_w) {
+                   const Bases &bases, int tag, int uniform_w, const RowOp *h_single) {
     if (nops <= 0 || max_slices <= 0) return;
     dim3 grid((max_slices + 3) / 4, nops);
+    if (nops != 1) h_single = nullptr;
     if (R != 2) {
-        launch_one<1, 0>(s, grid, d_ops, bases, tag);
+        launch_one<1, 0>(s, grid, d_ops, bases, tag, h_single);
         return;
     }
     switch (uniform_w) {
-#define KKT_W(n) case n: launch_one<2, n>(s, grid, d_ops, bases, tag); break;
+#define KKT_W(n) case n: launch_one<2, n>(s, grid, d_ops, bases, tag, h_single); break;
         KKT_W(1) KKT_W(2) KKT_W(3) KKT_W(4) KKT_W(5) KKT_W(6) KKT_W(7) KKT_W(8)
         KKT_W(9) KKT_W(10) KKT_W(11) KKT_W(12) KKT_W(13) KKT_W(14) KKT_W(15) KKT_W(16)
 #undef KKT_W
-        default: launch_one<2, 0>(s, grid, d_ops, bases, tag); break;
+        default: launch_one<2, 0>(s, grid, d_ops, bases, tag, h_single); break;
     }
 }
 

@@ -38,6 +38,7 @@ struct RowOp {
     int32_t pad0_;
     SpmvTerm t[MAX_TERMS];
     VRef y;
+    VRef y2;                   // EPI_LIN only, optional: y2 = c3 * dinv * y
     // EPI_LIN:  y = ca*acc + cy*yin + cz*z;  masked rows: y = malpha * mx[r] (0 if !mx)
     double ca, cy, cz;
     VRef yin, z;
@@ -52,7 +53,8 @@ struct RowOp {
 };
 
 void launch_rowops(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, int R,
-                   const Bases &bases, int tag, int uniform_w);
+                   const Bases &bases, int tag, int uniform_w,
+                   const RowOp *h_single = nullptr);
 
 // ---- value-array preparation
 void launch_csr_to_sell(hipStream_t s, const double *csr_vals, const int32_t *sell2csr,

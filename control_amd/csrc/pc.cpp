@@ -17,7 +17,6 @@ SchurPC::SchurPC(System &S, const kkt_pc_desc &d) : S_(S), d_(d) {
     if (!d.m_indptr || !d.m_indices || !d.m_values) fail(KKT_ERR_ARG, "mass matrix missing");
     if (S.nx0 != S.nx1 || d.nx != S.nx0)
         fail(KKT_ERR_ARG, "built-in preconditioner needs equal spatial spaces of size nx");
-    if (S.sharded) fail(KKT_ERR_STATE, "built-in preconditioner on a time-sharded system: TODO");
     nx_ = d.nx;
     if (d.kind == KKT_PC_STATIONARY)
         n_ = 1;
@@ -25,6 +24,8 @@ SchurPC::SchurPC(System &S, const kkt_pc_desc &d) : S_(S), d_(d) {
         n_ = d.kind == KKT_PC_INSTATIONARY_BE ? d.n_t : d.n_t - 1;
     if (n_ != S.n0 || n_ != S.n1 || n_ < 1)
         fail(KKT_ERR_ARG, "n_t does not match the block counts of the system");
+    lo_ = S.sharded ? S.lo : 0;
+    hi_ = S.sharded ? S.hi : n_;
     if (d.kind != KKT_PC_STATIONARY && n_ < 2) fail(KKT_ERR_ARG, "need at least two blocks");
     if (d.mass_its < 0 || d.schur_its < 0) fail(KKT_ERR_ARG, "negative Chebyshev degree");
     if ((d.mass_its > 0 && !(d.mass_emax > d.mass_emin && d.mass_emin > 0)) ||
@@ -50,10 +51,11 @@ SchurPC::~SchurPC() {
 }
 
 void SchurPC::clear_program() {
-    if (exec_) (void)hipGraphExecDestroy(exec_);
-    if (graph_) (void)hipGraphDestroy(graph_);
-    exec_ = nullptr;
-    graph_ = nullptr;
+    for (Segment &g : segments_) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    segments_.clear();
     for (auto &s : steps_)
         if (s.kind == PcStep::ROWS && s.rows.d_ops) (void)hipFree(s.rows.d_ops);
     steps_.clear();
@@ -116,11 +118,15 @@ void SchurPC::build() {
         owned_.push_back(p);
         return p;
     };
-    in_ = vec(2 * n_);
-    out_ = vec(2 * n_);
-    B_ = vec(n_);
-    T_ = vec(n_);
-    for (int k = 0; k < 3; ++k) P_[k] = vec(n_);
+    const int nl = hi_ - lo_;
+    in_ = vec(2 * nl);
+    out_ = vec(2 * nl);
+    B_ = vec(nl);
+    T_ = vec(nl);
+    for (int k = 0; k < 3; ++k) P_[k] = vec(nl);
+    h_u0_ = vec(1);
+    h_u1_ = vec(1);
+    h_t_ = vec(1);
     values_changed();
 }
 
@@ -144,6 +150,26 @@ SchurPC::Mat SchurPC::schur_matrix(const double *base_vals, double c) {
     return m;
 }
 
+void SchurPC::push_rows(std::vector<RowOp> &r) {
+    const Pattern &P = S_.patterns[m_pat_];
+    PcStep s;
+    s.kind = PcStep::ROWS;
+    s.rows.nops = (int)r.size();
+    s.rows.max_slices = P.nslices;
+    s.rows.R = P.R;
+    s.rows.uniform_w = P.uniform_w;
+    s.rows.d_ops = dev_upload(r.data(), r.size());
+    static const bool kernarg_ops = [] {
+        const char *e = std::getenv("KKT_KERNARG_OPS");
+        return e && e[0] == '1';
+    }();
+    if (r.size() == 1 && kernarg_ops) {
+        s.rows.single = true;
+        s.rows.h_op = r[0];
+    }
+    steps_.push_back(s);
+}
+
 void SchurPC::emit_lin(const std::vector<Lin> &ops) {
     const Pattern &P = S_.patterns[m_pat_];
     std::vector<RowOp> r;
@@ -162,6 +188,9 @@ void SchurPC::emit_lin(const std::vector<Lin> &ops) {
             op.t[t].x = vabs(l.terms[t].x);
         }
         op.y = vabs(l.y);
+        op.y2 = vabs(l.y2);
+        op.dinv = l.dinv;
+        op.c3 = l.c3;
         op.ca = l.ca;
         op.cy = l.cy;
         op.cz = l.cz;
@@ -172,14 +201,7 @@ void SchurPC::emit_lin(const std::vector<Lin> &ops) {
         op.b = op.pk = op.pkm1 = vabs(nullptr);
         r.push_back(op);
     }
-    PcStep s;
-    s.kind = PcStep::ROWS;
-    s.rows.nops = (int)r.size();
-    s.rows.max_slices = P.nslices;
-    s.rows.R = P.R;
-    s.rows.uniform_w = P.uniform_w;
-    s.rows.d_ops = dev_upload(r.data(), r.size());
-    steps_.push_back(s);
+    push_rows(r);
 }
 
 void SchurPC::emit_cheb(const std::vector<Cheb> &ops) {
@@ -199,6 +221,7 @@ void SchurPC::emit_cheb(const std::vector<Cheb> &ops) {
             op.t[0].x = vabs(c.pk);
         }
         op.y = vabs(c.y);
+        op.y2 = vabs(nullptr);
         op.yin = op.z = op.mx = vabs(nullptr);
         op.rowmask = mask_;
         op.b = vabs(c.b);
@@ -212,17 +235,11 @@ void SchurPC::emit_cheb(const std::vector<Cheb> &ops) {
         op.post2 = c.post2;
         r.push_back(op);
     }
-    PcStep s;
-    s.kind = PcStep::ROWS;
-    s.rows.nops = (int)r.size();
-    s.rows.max_slices = P.nslices;
-    s.rows.R = P.R;
-    s.rows.uniform_w = P.uniform_w;
-    s.rows.d_ops = dev_upload(r.data(), r.size());
-    steps_.push_back(s);
+    push_rows(r);
 }
 
-void SchurPC::emit_time(double *y, const double *x, int kind, int n) {
+void SchurPC::emit_time(double *y, const double *x, int kind, int n, const double *lo_halo,
+                        const double *hi_halo) {
     PcStep s;
     s.kind = PcStep::TIME;
     s.y = y;
@@ -230,13 +247,30 @@ void SchurPC::emit_time(double *y, const double *x, int kind, int n) {
     s.tkind = kind;
     s.n = n;
     s.nx = nx_;
+    s.lo_halo = lo_halo;
+    s.hi_halo = hi_halo;
     steps_.push_back(s);
 }
 
 // KSPSolve_Chebyshev (first kind) + PCJACOBI, zero initial guess, exactly `its` steps
 // (options of control.py:1973-1982); its == 0: one Jacobi application (control.py:1984-1991).
+void SchurPC::emit_update_and_solve(Lin upd, const Solve &sv, int its, double emin, double emax) {
+    if (its == 0) {
+        upd.y2 = sv.out;        // Jacobi: u = D^-1 b
+        upd.dinv = sv.dinv;
+        upd.c3 = 1.0;
+        emit_lin({upd});
+        return;
+    }
+    upd.y2 = its == 1 ? sv.out : P_[0];
+    upd.dinv = sv.dinv;
+    upd.c3 = 2.0 / (emax + emin);
+    emit_lin({upd});
+    emit_solves({sv}, its, emin, emax, P_, nx_, true);
+}
+
 void SchurPC::emit_solves(const std::vector<Solve> &sv, int its, double emin, double emax,
-                          double *const P[3], int64_t pstride) {
+                          double *const P[3], int64_t pstride, bool first_done) {
     const size_t m = sv.size();
     std::vector<Cheb> ops(m);
     if (its == 0) {
@@ -255,12 +289,14 @@ void SchurPC::emit_solves(const std::vector<Solve> &sv, int its, double emin, do
     auto target = [&](int step, size_t q) -> double * {
         return step == its ? sv[q].out : P[(step - 1) % 3] + (int64_t)q * pstride;
     };
-    for (size_t q = 0; q < m; ++q) {
-        const bool last = its == 1;
-        ops[q] = Cheb{nullptr, sv[q].dinv, sv[q].b, nullptr, nullptr, target(1, q),
-                      0.0, 0.0, scale, last ? sv[q].post1 : 1.0, last ? sv[q].post2 : 1.0};
+    if (!first_done) {
+        for (size_t q = 0; q < m; ++q) {
+            const bool last = its == 1;
+            ops[q] = Cheb{nullptr, sv[q].dinv, sv[q].b, nullptr, nullptr, target(1, q),
+                          0.0, 0.0, scale, last ? sv[q].post1 : 1.0, last ? sv[q].post2 : 1.0};
+        }
+        emit_cheb(ops);
     }
-    emit_cheb(ops);
     for (int step = 2; step <= its; ++step) {
         const double c_kp1 = 2.0 * mu * c_k - c_km1;
         const double omega = omegaprod * c_k / c_kp1;
@@ -293,29 +329,39 @@ void SchurPC::build_stationary() {
     emit_solves({Solve{S2.vals, S2.dinv, B_, u1}}, d_.schur_its, d_.schur_emin, d_.schur_emax, P_, nx_);
 }
 
+// Time sharding: a rank owns blocks [lo, hi).  Everything that is independent
+// per time level (mass solves, residual products) runs on the local blocks; the sweeps and
+// the CN scans are serial in time, so ranks hand one N_x vector to the next rank and form a
+// pipeline -- COMM steps between graph-captured segments of the program.
+
 // ---- Control.Instationary.construct_pc, BE branch, control.py:2191-2438
 void SchurPC::build_BE() {
-    const int n = n_;
+    const int n = n_, lo = lo_, hi = hi_;
     const double tau = d_.tau, eps = d_.epsilon;
     const double shift = tau / std::sqrt(d_.beta);
-    double *b0 = in_, *b1 = in_ + (int64_t)n * nx_;
-    double *u0 = out_, *u1 = out_ + (int64_t)n * nx_;
-    auto blk = [&](double *base, int i) { return base + (int64_t)i * nx_; };
+    const int64_t nl = hi - lo;
+    double *b0 = in_, *b1 = in_ + nl * nx_;
+    double *u0 = out_, *u1 = out_ + nl * nx_;
+    auto blk = [&](double *base, int i) { return base + (int64_t)(i - lo) * nx_; };
+    const int up = hi < n ? S_.rank + 1 : -1, dn = lo > 0 ? S_.rank - 1 : -1;
     // (1,1)-block: u0_i = (1/tau) M~^-1 b0_i, last one also / epsilon   (2193-2206)
     {
         std::vector<Solve> sv;
-        for (int i = 0; i < n; ++i)
+        for (int i = lo; i < hi; ++i)
             sv.push_back(Solve{m_vals_, m_dinv_, blk(b0, i), blk(u0, i), 1.0 / tau,
                                i == n - 1 ? 1.0 / eps : 1.0});
         emit_solves(sv, d_.mass_its, d_.mass_emin, d_.mass_emax, P_, nx_);
     }
+    if (up >= 0 || dn >= 0) emit_comm(blk(u0, hi - 1), up, h_u0_, dn);
     // b_i = block_10(i,i) u0_i + block_10(i,i-1) u0_{i-1} - b1_i   (2208-2237)
     {
         std::vector<Lin> ops;
-        for (int i = 0; i < n; ++i) {
+        for (int i = lo; i < hi; ++i) {
             Lin l;
             l.terms.push_back(Term{block_vals(KKT_Q10, i, i), blk(u0, i)});
-            if (i >= 1) l.terms.push_back(Term{block_vals(KKT_Q10, i, i - 1), blk(u0, i - 1)});
+            if (i >= 1)
+                l.terms.push_back(Term{block_vals(KKT_Q10, i, i - 1),
+                                       i - 1 >= lo ? blk(u0, i - 1) : h_u0_});
             l.y = blk(B_, i);
             l.cz = -1.0;
             l.z = blk(b1, i);
@@ -325,141 +371,213 @@ void SchurPC::build_BE() {
     }
     auto coef = [&](int i) { return i == 0 ? 0.0 : (i == n - 1 ? std::sqrt(eps) * shift : shift); };
     // forward sweep (2241-2327)
-    for (int i = 0; i < n; ++i) {
-        if (i >= 1)
-            emit_lin({Lin{{Term{block_vals(KKT_Q10, i, i - 1), blk(u1, i - 1)}}, blk(B_, i), -1.0,
-                          1.0, 0.0, blk(B_, i), nullptr}});
+    if (dn >= 0) emit_comm(nullptr, -1, h_u1_, dn);
+    for (int i = lo; i < hi; ++i) {
         Mat F = schur_matrix(block_vals(KKT_Q10, i, i), coef(i));
-        emit_solves({Solve{F.vals, F.dinv, blk(B_, i), blk(u1, i)}}, d_.schur_its, d_.schur_emin,
-                    d_.schur_emax, P_, nx_);
+        const Solve sv{F.vals, F.dinv, blk(B_, i), blk(u1, i)};
+        if (i >= 1)
+            emit_update_and_solve(Lin{{Term{block_vals(KKT_Q10, i, i - 1),
+                                            i - 1 >= lo ? blk(u1, i - 1) : h_u1_}},
+                                      blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i), nullptr},
+                                  sv, d_.schur_its, d_.schur_emin, d_.schur_emax);
+        else
+            emit_solves({sv}, d_.schur_its, d_.schur_emin, d_.schur_emax, P_, nx_);
     }
+    if (up >= 0) emit_comm(blk(u1, hi - 1), up, nullptr, -1);
     // b_i = tau M u1_i (epsilon tau for the last)   (2330-2350)
     {
         std::vector<Lin> ops;
-        for (int i = 0; i < n; ++i)
+        for (int i = lo; i < hi; ++i)
             ops.push_back(Lin{{Term{m_vals_, blk(u1, i)}}, blk(B_, i),
                               i == n - 1 ? eps * tau : tau});
         emit_lin(ops);
     }
     // backward sweep (2353-2437)
-    for (int i = n - 1; i >= 0; --i) {
-        if (i <= n - 2)
-            emit_lin({Lin{{Term{block_vals(KKT_Q01, i, i + 1), blk(u1, i + 1)}}, blk(B_, i), -1.0,
-                          1.0, 0.0, blk(B_, i), nullptr}});
+    if (up >= 0) emit_comm(nullptr, -1, h_u1_, up);
+    for (int i = hi - 1; i >= lo; --i) {
         Mat G = schur_matrix(block_vals(KKT_Q01, i, i), coef(i));
-        emit_solves({Solve{G.vals, G.dinv, blk(B_, i), blk(u1, i)}}, d_.schur_its, d_.schur_emin,
-                    d_.schur_emax, P_, nx_);
+        const Solve sv{G.vals, G.dinv, blk(B_, i), blk(u1, i)};
+        if (i <= n - 2)
+            emit_update_and_solve(Lin{{Term{block_vals(KKT_Q01, i, i + 1),
+                                            i + 1 < hi ? blk(u1, i + 1) : h_u1_}},
+                                      blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i), nullptr},
+                                  sv, d_.schur_its, d_.schur_emin, d_.schur_emax);
+        else
+            emit_solves({sv}, d_.schur_its, d_.schur_emin, d_.schur_emax, P_, nx_);
     }
+    if (dn >= 0) emit_comm(blk(u1, lo), dn, nullptr, -1);
 }
 
 // ---- Control.Instationary.construct_pc, CN branch, control.py:1995-2189
 void SchurPC::build_CN() {
-    const int n = n_;
+    const int n = n_, lo = lo_, hi = hi_;
     const double tau = d_.tau;
     const double c = 0.5 * tau / std::sqrt(d_.beta);   // my_const, control.py:2051
-    double *b0 = in_, *b1 = in_ + (int64_t)n * nx_;
-    double *u0 = out_, *u1 = out_ + (int64_t)n * nx_;
-    auto blk = [&](double *base, int i) { return base + (int64_t)i * nx_; };
+    const int64_t nl = hi - lo;
+    const int nloc = (int)nl;
+    double *b0 = in_, *b1 = in_ + nl * nx_;
+    double *u0 = out_, *u1 = out_ + nl * nx_;
+    auto blk = [&](double *base, int i) { return base + (int64_t)(i - lo) * nx_; };
+    const int up = hi < n ? S_.rank + 1 : -1, dn = lo > 0 ? S_.rank - 1 : -1;
     Mat cM = schur_matrix(nullptr, c);   // c * M~ (base absent): products with my_const * M
-    // (1,1)-block (1997-2014)
-    emit_time(T_, b0, 3, n);   // T_1^-1
+    // (1,1)-block (1997-2014): T_1^-1 is a scan from the last block down
+    if (up >= 0) emit_comm(nullptr, -1, h_t_, up);
+    emit_time(T_, b0, 3, nloc, nullptr, up >= 0 ? h_t_ : nullptr);
+    if (dn >= 0) emit_comm(blk(T_, lo), dn, nullptr, -1);
     {
         std::vector<Solve> sv;
-        for (int i = 0; i < n; ++i)
+        for (int i = lo; i < hi; ++i)
             sv.push_back(Solve{m_vals_, m_dinv_, blk(T_, i), blk(u0, i), 2.0 / tau, 1.0});
         emit_solves(sv, d_.mass_its, d_.mass_emin, d_.mass_emax, P_, nx_);
     }
-    emit_time(u0, u0, 4, n);   // T_2^-1
+    // T_2^-1: scan from the first block up; afterwards h_u0_ holds the final u0_{lo-1}
+    if (dn >= 0) emit_comm(nullptr, -1, h_u0_, dn);
+    emit_time(u0, u0, 4, nloc, dn >= 0 ? h_u0_ : nullptr, nullptr);
+    if (up >= 0) emit_comm(blk(u0, hi - 1), up, nullptr, -1);
     // b = T_2 (D_v u0) - b1 (2016-2048)
     {
         std::vector<Lin> ops;
-        for (int i = 0; i < n; ++i) {
+        for (int i = lo; i < hi; ++i) {
             Lin l;
             l.terms.push_back(Term{block_vals(KKT_Q10, i, i), blk(u0, i)});
-            if (i >= 1) l.terms.push_back(Term{block_vals(KKT_Q10, i, i - 1), blk(u0, i - 1)});
+            if (i >= 1)
+                l.terms.push_back(Term{block_vals(KKT_Q10, i, i - 1),
+                                       i - 1 >= lo ? blk(u0, i - 1) : h_u0_});
             l.y = blk(B_, i);
             ops.push_back(l);
         }
         emit_lin(ops);
     }
-    emit_time(B_, B_, 2, n);
+    if (up >= 0 || dn >= 0) emit_comm(blk(B_, hi - 1), up, h_t_, dn);   // old values
+    emit_time(B_, B_, 2, nloc, dn >= 0 ? h_t_ : nullptr, nullptr);
     {
         std::vector<Lin> ops;
-        for (int i = 0; i < n; ++i)
+        for (int i = lo; i < hi; ++i)
             ops.push_back(Lin{{}, blk(B_, i), 0.0, 1.0, -1.0, blk(B_, i), blk(b1, i)});
         emit_lin(ops);
     }
     // forward sweep (2050-2116)
-    emit_time(B_, B_, 4, n);
-    for (int i = 0; i < n; ++i) {
-        if (i >= 1)
-            emit_lin({Lin{{Term{block_vals(KKT_Q10, i, i - 1), blk(u1, i - 1)},
-                           Term{cM.vals, blk(u1, i - 1)}},
-                          blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i), nullptr}});
+    if (dn >= 0) emit_comm(nullptr, -1, h_t_, dn);
+    emit_time(B_, B_, 4, nloc, dn >= 0 ? h_t_ : nullptr, nullptr);
+    if (up >= 0) emit_comm(blk(B_, hi - 1), up, nullptr, -1);
+    if (dn >= 0) emit_comm(nullptr, -1, h_u1_, dn);
+    for (int i = lo; i < hi; ++i) {
         Mat F = schur_matrix(block_vals(KKT_Q10, i, i), c);
-        emit_solves({Solve{F.vals, F.dinv, blk(B_, i), blk(u1, i)}}, d_.schur_its, d_.schur_emin,
-                    d_.schur_emax, P_, nx_);
+        const Solve sv{F.vals, F.dinv, blk(B_, i), blk(u1, i)};
+        if (i >= 1) {
+            const double *prev = i - 1 >= lo ? blk(u1, i - 1) : h_u1_;
+            emit_update_and_solve(Lin{{Term{block_vals(KKT_Q10, i, i - 1), prev},
+                                       Term{cM.vals, prev}},
+                                      blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i), nullptr},
+                                  sv, d_.schur_its, d_.schur_emin, d_.schur_emax);
+        } else {
+            emit_solves({sv}, d_.schur_its, d_.schur_emin, d_.schur_emax, P_, nx_);
+        }
     }
-    // u1 = T_2 u1; b_i = (tau/2) M u1_i (2118-2133)
-    emit_time(u1, u1, 2, n);
+    if (up >= 0) emit_comm(blk(u1, hi - 1), up, nullptr, -1);
+    // u1 = T_2 u1 (h_u1_ still holds the untransformed u1_{lo-1}); b_i = (tau/2) M u1_i
+    emit_time(u1, u1, 2, nloc, dn >= 0 ? h_u1_ : nullptr, nullptr);
     {
         std::vector<Lin> ops;
-        for (int i = 0; i < n; ++i)
+        for (int i = lo; i < hi; ++i)
             ops.push_back(Lin{{Term{m_vals_, blk(u1, i)}}, blk(B_, i), 0.5 * tau});
         emit_lin(ops);
     }
     // backward sweep (2135-2189)
-    for (int i = n - 1; i >= 0; --i) {
+    if (up >= 0) emit_comm(nullptr, -1, h_u1_, up);
+    for (int i = hi - 1; i >= lo; --i) {
+        Mat G = schur_matrix(block_vals(KKT_Q01, i, i), c);
+        const Solve sv{G.vals, G.dinv, blk(B_, i), blk(u1, i)};
         if (i <= n - 2) {
             Mat H = schur_matrix(block_vals(KKT_Q01, i, i + 1), c);
-            emit_lin({Lin{{Term{H.vals, blk(u1, i + 1)}}, blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i),
-                          nullptr}});
+            emit_update_and_solve(Lin{{Term{H.vals, i + 1 < hi ? blk(u1, i + 1) : h_u1_}},
+                                      blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i), nullptr},
+                                  sv, d_.schur_its, d_.schur_emin, d_.schur_emax);
+        } else {
+            emit_solves({sv}, d_.schur_its, d_.schur_emin, d_.schur_emax, P_, nx_);
         }
-        Mat G = schur_matrix(block_vals(KKT_Q01, i, i), c);
-        emit_solves({Solve{G.vals, G.dinv, blk(B_, i), blk(u1, i)}}, d_.schur_its, d_.schur_emin,
-                    d_.schur_emax, P_, nx_);
     }
+    if (dn >= 0) emit_comm(blk(u1, lo), dn, nullptr, -1);
 }
 
-void SchurPC::replay() {
+void SchurPC::emit_comm(const double *send, int dst, double *recv, int src) {
+    PcStep s;
+    s.kind = PcStep::COMM;
+    s.x = send;
+    s.y = recv;
+    s.dst = dst;
+    s.src = src;
+    s.nx = nx_;
+    steps_.push_back(s);
+}
+
+void SchurPC::replay(size_t first, size_t last) {
     hipStream_t st = S_.stream;
     Bases B{{nullptr, nullptr, nullptr, nullptr}};
-    for (const PcStep &s : steps_) {
+    for (size_t k = first; k < last; ++k) {
+        const PcStep &s = steps_[k];
         switch (s.kind) {
             case PcStep::ROWS:
                 launch_rowops(st, s.rows.d_ops, s.rows.nops, s.rows.max_slices, s.rows.R, B, 1,
-                              s.rows.uniform_w);
+                              s.rows.uniform_w, s.rows.single ? &s.rows.h_op : nullptr);
                 break;
             case PcStep::TIME:
-                launch_time_transform(st, s.y, s.x, s.tkind, s.n, s.nx, nullptr, nullptr);
+                launch_time_transform(st, s.y, s.x, s.tkind, s.n, s.nx, s.lo_halo, s.hi_halo);
                 break;
             case PcStep::COPY:
                 launch_copy(st, s.y, s.x, s.nx);
                 break;
+            case PcStep::COMM:
+                if (!S_.comm) fail(KKT_ERR_STATE, "time-sharded system without a transport");
+                S_.comm->sendrecv(s.x, s.nx, s.dst, s.y, s.nx, s.src, st);
+                break;
         }
     }
 }
 
+// The program is a fixed launch sequence on fixed buffers: every maximal run of kernel
+// steps between two COMM steps is captured once into a hipGraph and replayed.
 void SchurPC::run() {
     hipStream_t st = S_.stream;
-    if (use_graph_ && !exec_) {
-        // the program is a fixed launch sequence on fixed buffers: capture it once
-        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-        if (e == hipSuccess) {
-            replay();
-            e = hipStreamEndCapture(st, &graph_);
-            if (e == hipSuccess) e = hipGraphInstantiate(&exec_, graph_, nullptr, nullptr, 0);
-        }
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            exec_ = nullptr;
-            use_graph_ = false;   // plain launches of the same kernels
+    if (segments_.empty()) {
+        size_t k = 0;
+        while (k < steps_.size()) {
+            Segment g;
+            g.first = k;
+            if (steps_[k].kind == PcStep::COMM) {
+                g.last = k + 1;
+                g.comm = true;
+            } else {
+                size_t e = k;
+                while (e < steps_.size() && steps_[e].kind != PcStep::COMM) ++e;
+                g.last = e;
+            }
+            k = g.last;
+            segments_.push_back(g);
         }
     }
-    if (exec_)
-        HIPCHK(hipGraphLaunch(exec_, st));
-    else
-        replay();
+    for (Segment &g : segments_) {
+        if (g.comm || !use_graph_ || g.last - g.first < 4) {
+            replay(g.first, g.last);
+            continue;
+        }
+        if (!g.exec) {
+            hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                replay(g.first, g.last);
+                e = hipStreamEndCapture(st, &g.graph);
+                if (e == hipSuccess) e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+            }
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                g.exec = nullptr;
+                use_graph_ = false;   // plain launches of the same kernels
+                replay(g.first, g.last);
+                continue;
+            }
+        }
+        HIPCHK(hipGraphLaunch(g.exec, st));
+    }
 }
 
 }  // namespace kkt

@@ -5,17 +5,20 @@
 #include <map>
 #include <vector>
 
+#include "comm.hpp"
 #include "system.hpp"
 
 namespace kkt {
 
 struct PcStep {
-    enum Kind { ROWS, TIME, COPY } kind;
+    enum Kind { ROWS, TIME, COPY, COMM } kind;
     RowLaunch rows;                 // ROWS
     double *y = nullptr;            // TIME / COPY
     const double *x = nullptr;
     int tkind = 0, n = 0;
-    int64_t nx = 0;                 // TIME: block length; COPY: element count
+    int64_t nx = 0;                 // TIME: block length; COPY / COMM: element count
+    const double *lo_halo = nullptr, *hi_halo = nullptr;   // TIME on a time shard
+    int dst = -1, src = -1;         // COMM: send x to dst, receive y from src
 };
 
 class SchurPC {
@@ -35,7 +38,8 @@ class SchurPC {
     kkt_pc_desc d_;
     std::vector<int32_t> m_indptr_, m_indices_, bc_idx_;
     std::vector<double> m_values_;
-    int n_ = 1;                // blocks per variable
+    int n_ = 1;                // blocks per variable (global)
+    int lo_ = 0, hi_ = 1;      // owned block range
     int64_t nx_ = 0;
     int bc_set_ = -1;
     const uint8_t *mask_ = nullptr;
@@ -52,9 +56,15 @@ class SchurPC {
         double *dinv;
     };
     std::map<std::pair<const double *, uint64_t>, Mat> mats_;
+    double *h_u0_ = nullptr, *h_u1_ = nullptr, *h_t_ = nullptr;   // one-block halos
     std::vector<PcStep> steps_;
-    hipGraph_t graph_ = nullptr;
-    hipGraphExec_t exec_ = nullptr;
+    struct Segment {
+        size_t first = 0, last = 0;
+        bool comm = false;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+    };
+    std::vector<Segment> segments_;
     bool use_graph_ = true;
 
     struct Term {
@@ -66,6 +76,10 @@ class SchurPC {
         double *y;
         double ca = 1.0, cy = 0.0, cz = 0.0;
         const double *yin = nullptr, *z = nullptr;
+        // optional fused first Chebyshev step of the solve that follows: y2 = c3 * dinv * y
+        double *y2 = nullptr;
+        const double *dinv = nullptr;
+        double c3 = 0.0;
     };
     struct Cheb {
         const double *vals;   // nullptr: no matrix term (first step)
@@ -79,7 +93,9 @@ class SchurPC {
     Mat schur_matrix(const double *base_vals, double c);
     void emit_lin(const std::vector<Lin> &ops);
     void emit_cheb(const std::vector<Cheb> &ops);
-    void emit_time(double *y, const double *x, int kind, int n);
+    void emit_time(double *y, const double *x, int kind, int n, const double *lo_halo = nullptr,
+                   const double *hi_halo = nullptr);
+    void emit_comm(const double *send, int dst, double *recv, int src);
     // its-step Jacobi-Chebyshev solves of `count` independent systems in lock step
     struct Solve {
         const double *vals, *dinv, *b;
@@ -87,11 +103,15 @@ class SchurPC {
         double post1 = 1.0, post2 = 1.0;
     };
     void emit_solves(const std::vector<Solve> &sv, int its, double emin, double emax,
-                     double *const P[3], int64_t pstride);
+                     double *const P[3], int64_t pstride, bool first_done = false);
+    // the sweep step "b -= A u_prev (masked), then solve": the update and the first
+    // Chebyshev step share one launch
+    void emit_update_and_solve(Lin upd, const Solve &sv, int its, double emin, double emax);
+    void push_rows(std::vector<RowOp> &r);
     void build_stationary();
     void build_BE();
     void build_CN();
-    void replay();
+    void replay(size_t first, size_t last);
 };
 
 }  // namespace kkt

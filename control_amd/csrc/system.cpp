@@ -391,6 +391,7 @@ void System::finalize() {
                 op.mode = EPI_LIN;
                 op.nrows = (int32_t)nxr;
                 op.y = vref(2, yoff);
+                op.y2 = vnull();
                 op.ca = 1.0;
                 op.cy = 1.0;
                 op.cz = 0.0;

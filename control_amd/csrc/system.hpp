@@ -85,6 +85,8 @@ struct RowLaunch {
     int max_slices = 0;
     int R = 2;
     int uniform_w = -1;   // > 0: every op with terms in this launch has this slice width
+    bool single = false;  // nops == 1: h_op rides in the kernel arguments
+    RowOp h_op;
 };
 
 struct TimeGroup {   // CN transform applied to a contiguous range of local blocks
