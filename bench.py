@@ -33,6 +33,21 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def measured_traffic(workload):
+    """HBM bytes per kkt_spmv_rows launch from the committed rocprofv3 --pmc passes
+    (profiles/*/traffic_kkt_spmv_rows.json), for this exact workload; else None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic_kkt_spmv_rows.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("workload") == workload:
+            best = d.get("hbm_bytes_per_launch_corrected")
+    return best
+
+
 def build_problem(args):
     from control_amd.blocks import instationary_blocks
     from control_amd.fem import unit_cube_p1, unit_square_p1
@@ -91,6 +106,8 @@ def main():
     ap.add_argument("--spmv-reps", type=int, default=50)
     ap.add_argument("--cpu-its", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only-spmv", action="store_true",
+                    help="time the KKT SpMV only (counter-collection passes)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,6 +150,11 @@ def main():
     spmv_ms = ms.value / args.spmv_reps
     alg_bytes = info["bytes_algorithmic"]
     achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9
+    if args.only_spmv:
+        if rank == 0:
+            print(json.dumps({"kkt_apply_ms": spmv_ms, "achieved_GBs": achieved,
+                              "algorithmic_bytes_per_launch": alg_bytes}))
+        return
     gsys._ck(lib.kkt_time_pc_apply(h, d_x, d_y, 2, C.byref(ms)))
     gsys._ck(lib.kkt_time_pc_apply(h, d_x, d_y, 5, C.byref(ms)))
     pc_ms = ms.value / 5
@@ -162,6 +184,9 @@ def main():
 
     if rank != 0:
         return
+    workload = (f"{'2-D' if args.workload == 'heat2d' else '3-D'} heat control, "
+                f"{args.n}^{2 if args.workload == 'heat2d' else 3} P1, n_t={args.n_t}, "
+                f"beta={args.beta:g}, T={args.T:g}, {args.scheme}, mode {args.mode}")
     out = {
         "metric": "Krylov iterations/s (preconditioned GMRES(10), all-at-once heat-control KKT)",
         "value": its / dt, "unit": "Krylov iterations/s", "n_gpus": world,
@@ -169,9 +194,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": (f"{'2-D' if args.workload == 'heat2d' else '3-D'} heat control, "
-                         f"{args.n}^{2 if args.workload == 'heat2d' else 3} P1, n_t={args.n_t}, "
-                         f"beta={args.beta:g}, T={args.T:g}, {args.scheme}, mode {args.mode}"),
+            "workload": workload,
             "unknowns": int(2 * p["m"] * p["sd"].n_dofs),
             "krylov": "gmres, left preconditioning, restart 10, classical Gram-Schmidt",
             "preconditioner": (f"block Schur: mass Chebyshev {p['mass']}, "
@@ -181,7 +204,8 @@ def main():
         "roofline": {
             "kernel": "kkt_spmv_rows (fused block-row SpMV of the KKT operator)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": measured_traffic(workload) if world == 1 else None,
             "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": spmv_ms,
             "device_bytes_per_launch": (info["bytes_device_values"]
                                         + info["bytes_device_index"] // max(1, info["n_patterns"])
