@@ -1,0 +1,71 @@
+"""Golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py from the CPU
+oracle): the oracle must keep reproducing them (CPU), and the HIP path must match them
+through the C-ABI (GPU) -- no oracle code runs in the GPU variants."""
+import os
+
+import numpy as np
+import pytest
+
+import common
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MASS, SCHUR, KSCHUR = (20, 0.5, 2.0), (10, 0.2, 2.1), (12, 0.08, 2.1)
+SP = {"gmres_restart": 10, "maximum_iterations": 60, "relative_tolerance": 1e-6,
+      "absolute_tolerance": 0.0, "monitor_convergence": False, "preconditioner": True}
+
+
+def load(CN):
+    return np.load(os.path.join(HERE, "golden", f"config1_{'CN' if CN else 'BE'}.npz"))
+
+
+@pytest.mark.parametrize("CN", [False, True])
+def test_oracle_reproduces_golden(CN):
+    g = load(CN)
+    p = common.heat_problem(n=10, n_t=10, CN=CN, beta=1e-4)
+    osys = common.oracle_system(p)
+    for x, Ax in zip(g["x"], g["Ax"]):
+        assert common.rel_err(osys.mult(x), Ax) < 1e-14
+    assert common.rel_err(osys.pc_apply(common.oracle_pc(p, MASS, SCHUR), g["x"][0]),
+                          g["pc_x"]) < 1e-12
+    q = common.heat_problem(n=10, n_t=10, CN=CN, beta=1e-2)
+    qsys = common.oracle_system(q)
+    m, nx = q["m"], q["sd"].n_dofs
+    b = g["krylov_b"]
+    if CN:      # BE histories are ill-conditioned even against BLAS thread-order changes
+        u0, u1 = np.zeros((m, nx)), np.zeros((m, nx))
+        r = qsys.solve(u0, u1, b[:m], b[m:], solver_parameters=dict(SP, linear_solver="gmres"),
+                       pc_fn=common.oracle_pc(q, MASS, KSCHUR))
+        assert r.its == int(g["gmres_its"])
+        assert np.max(np.abs(np.asarray(r.history) - g["gmres_history"])
+                      / g["gmres_history"]) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("CN", [False, True])
+def test_gpu_matches_golden(CN):
+    g = load(CN)
+    p = common.heat_problem(n=10, n_t=10, CN=CN, beta=1e-4)
+    gsys = common.gpu_system(p)
+    for x, Ax in zip(g["x"], g["Ax"]):
+        assert common.rel_err(gsys.mult(x), Ax) < 1e-13
+    assert common.rel_err(gsys.pc_apply(g["x"][0], common.gpu_pc(p, MASS, SCHUR)),
+                          g["pc_x"]) < 1e-10
+    q = common.heat_problem(n=10, n_t=10, CN=CN, beta=1e-2)
+    qsys = common.gpu_system(q)
+    m, nx = q["m"], q["sd"].n_dofs
+    b = g["krylov_b"]
+    for ksp in ("gmres", "fgmres"):
+        u0, u1 = np.zeros((m, nx)), np.zeros((m, nx))
+        r = qsys.solve(u0, u1, b[:m].copy(), b[m:].copy(),
+                       solver_parameters=dict(SP, linear_solver=ksp),
+                       pc_fn=common.gpu_pc(q, MASS, KSCHUR))
+        assert r.reason == int(g[f"{ksp}_reason"])
+        if CN:
+            assert r.its == int(g[f"{ksp}_its"])
+            h = g[f"{ksp}_history"]
+            assert np.max(np.abs(r.history - h) / h) < 1e-6
+            assert common.rel_err(np.vstack([u0, u1]), g[f"{ksp}_solution"]) < 1e-6
+        else:
+            assert abs(r.its - int(g[f"{ksp}_its"])) <= 1
+            if ksp == "fgmres":
+                assert common.rel_err(np.vstack([u0, u1]), g[f"{ksp}_solution"]) < 1e-5
