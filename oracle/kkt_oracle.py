@@ -199,7 +199,7 @@ class _ConvergedDefault:
 
 
 def _gmres_driver(A, B, b, x, *, restart, rtol, atol, divtol, max_it, flexible,
-                  right, monitor=None):
+                  right, monitor=None, reduce=None):
     """GMRES(m) / FGMRES(m), structured like ``KSPSolve_GMRES`` + ``KSPGMRESCycle``.
 
     left  (gmres default):  Krylov on B A, monitored norm ||B r||.
@@ -208,7 +208,17 @@ def _gmres_driver(A, B, b, x, *, restart, rtol, atol, divtol, max_it, flexible,
     n = b.size
     res = KSPResult()
     # KSPConvergedDefault at it == 0 with a nonzero guess: norm of the (preconditioned) rhs
-    rnorm0 = np.linalg.norm(b) if right else np.linalg.norm(B(b))
+    # `reduce` sums partial inner products over the ranks of a time-sharded run
+    # (oracle/dist_oracle.py); None = single rank
+    def mdot(Vk, w):
+        h = Vk @ w
+        return reduce(h) if reduce is not None else h
+
+    def vnorm(v):
+        return float(np.sqrt(mdot(v[None, :], v)[0])) if reduce is not None \
+            else np.linalg.norm(v)
+
+    rnorm0 = vnorm(b) if right else vnorm(B(b))
     conv = _ConvergedDefault(rtol, atol, divtol, rnorm0)
     haptol = 1.0e-30
     its = 0
@@ -224,7 +234,7 @@ def _gmres_driver(A, B, b, x, *, restart, rtol, atol, divtol, max_it, flexible,
         # KSPInitialResidual
         r = b - A(x)
         V[0] = r if right else B(r)
-        rn = np.linalg.norm(V[0])
+        rn = vnorm(V[0])
         res.history.append(rn)
         if monitor is not None:
             monitor(its, rn)
@@ -251,10 +261,10 @@ def _gmres_driver(A, B, b, x, *, restart, rtol, atol, divtol, max_it, flexible,
             else:
                 w = B(A(V[it]))
             # classical Gram-Schmidt, no refinement (VecMDot, VecMAXPY)
-            h = V[:it + 1] @ w
+            h = mdot(V[:it + 1], w)
             w = w - h @ V[:it + 1]
             H[:it + 1, it] = h
-            tt = np.linalg.norm(w)
+            tt = vnorm(w)
             hapbnd = min(abs(tt / grs[it]), haptol)
             hapend = tt < hapbnd
             if not hapend:
