@@ -66,6 +66,26 @@ def build_problem(args):
                 schur=(args.schur_its, args.schur_emin, args.schur_emax))
 
 
+def usable_cores():
+    """Host cores this process may really use: the scheduler affinity, capped by the cgroup
+    CPU quota (a one-GPU box grants a 16-core share of a much larger host)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, int(os.environ.get("KKT_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(p, args):
     """The C/OpenMP restatement of the same algorithm (oracle/csrc/kkt_ref.c: per-block CSR
     SpMV as PETSc's MatMultAdd_SeqAIJ, the same block-Schur preconditioner with the same
@@ -76,15 +96,20 @@ def cpu_baseline(p, args):
     from oracle import cref
     if p["CN"]:
         return None   # the C restatement covers the BE benchmark configuration
+    print("[bench] cpu baseline: building the C restatement's matrices", file=sys.stderr,
+          flush=True)
     c = cref.CRef(p["blocks"], p["m"], p["sd"].n_dofs, p["nodes"], p["sd"].M, p["n_t"],
                   p["tau"], p["beta"], p["mass"], p["schur"])
     b = common.rng_vector(2 * p["m"] * p["sd"].n_dofs)
     gomp = ctypes.CDLL("libgomp.so.1")
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     out = {}
-    for threads, its in ((cores, args.cpu_its), (1, max(1, args.cpu_its // 4))):
+    for threads, its in ((cores, args.cpu_its), (1, max(1, args.cpu_its // 8))):
         gomp.omp_set_num_threads(threads)
-        c.gmres(b, np.zeros_like(b), rtol=0.0, max_it=1)          # warm-up, page-in
+        print(f"[bench] cpu baseline: {its} iterations on {threads} thread(s)",
+              file=sys.stderr, flush=True)
+        if threads == cores:
+            c.gmres(b, np.zeros_like(b), rtol=0.0, max_it=1)      # warm-up, page-in
         t0 = time.perf_counter()
         _, n_it, _, _ = c.gmres(b, np.zeros_like(b), rtol=0.0, divtol=1e300, max_it=its)
         dt = time.perf_counter() - t0
@@ -114,7 +139,7 @@ def main():
     ap.add_argument("--schur-emin", type=float, default=0.07)
     ap.add_argument("--schur-emax", type=float, default=2.1)
     ap.add_argument("--spmv-reps", type=int, default=50)
-    ap.add_argument("--cpu-its", type=int, default=12)
+    ap.add_argument("--cpu-its", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--only-spmv", action="store_true",
                     help="time the KKT SpMV only (counter-collection passes)")
@@ -133,6 +158,7 @@ def main():
     from control_amd import _lib
     from control_amd.dist import make_comm
 
+    print("[bench] assembling the synthetic system", file=sys.stderr, flush=True)
     p = build_problem(args)
     comm = make_comm(rank, world, local_rank) if world > 1 else None
     gsys = common.gpu_system(p, device=local_rank, comm=comm)
@@ -187,6 +213,8 @@ def main():
         gsys._ck(lib.kkt_comm_max(h, C.byref(dt)))
         return its.value, dt.value
 
+    print(f"[bench] spmv {spmv_ms:.3f} ms, pc {pc_ms:.3f} ms; Krylov leg", file=sys.stderr,
+          flush=True)
     if args.warmup > 0:
         run(args.warmup)
     its, dt = run(args.steps)

@@ -527,14 +527,19 @@ class OracleSystem:
 def assemble_with_bcs(A, nodes):
     """Firedrake ``assemble(form, bcs=...)``: bc rows/cols zeroed, unit diagonal."""
     A = sp.csr_matrix(A, copy=True)
+    A.sort_indices()
     n = A.shape[0]
     keep = np.ones(n)
     keep[nodes] = 0.0
-    Dk = sp.diags(keep)
-    At = Dk @ A @ Dk + sp.diags(1.0 - keep)
-    At = sp.csr_matrix(At)
-    At.sort_indices()
-    return At
+    rows = np.repeat(np.arange(n), np.diff(A.indptr))
+    A.data *= keep[rows] * keep[A.indices]
+    isdiag = (rows == A.indices) & (keep[rows] == 0.0)
+    if int(isdiag.sum()) != int((keep == 0.0).sum()):   # a bc row without a stored diagonal
+        A = sp.csr_matrix(A + sp.diags(1.0 - keep))
+        A.sort_indices()
+    else:
+        A.data[isdiag] = 1.0
+    return A
 
 
 @dataclass

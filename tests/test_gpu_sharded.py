@@ -58,3 +58,22 @@ def test_sharded_matches_oracle(world, CN):
     # every rank saw the same residual history (deterministic reductions)
     for r in range(1, world):
         assert res[r]["hist"] == res[0]["hist"]
+
+
+def test_rccl_transport_single_rank():
+    """RCCL is loaded, a communicator is created and the collectives used by bench.py
+    (barrier = all-reduce of one double, max) run -- world size 1, the only RCCL shape a
+    one-GPU box can execute; the multi-rank data path is the one tested above."""
+    import ctypes as C
+    import common
+    from control_amd import _lib
+    p = common.heat_problem(n=6, n_t=4)
+    gsys = common.gpu_system(p)
+    lib, h = gsys._lib, gsys.handle
+    uid = C.create_string_buffer(128)
+    assert lib.kkt_comm_unique_id(uid) == 0, lib.kkt_last_error(None)
+    assert lib.kkt_comm_init_rccl(h, uid) == 0, lib.kkt_last_error(h)
+    assert lib.kkt_comm_barrier(h) == 0, lib.kkt_last_error(h)
+    v = C.c_double(3.25)
+    assert lib.kkt_comm_max(h, C.byref(v)) == 0, lib.kkt_last_error(h)
+    assert v.value == 3.25
