@@ -22,9 +22,11 @@ __device__ __forceinline__ const double *resolve(const VRef &r, const Bases &B) 
 //
 // Layout ("SELL-64R"): rows are cut into slices of C = 64*R consecutive rows; slice s
 // has width w_s = max row length in it and owns slots [slice_off[s], slice_off[s+1]).
-// Entry k of row (s*C + lane*R + q) sits at (slice_off[s] + k)*C + lane*R + q, so one
+// Entry k of row (s*C + q*64 + lane) sits at (slice_off[s] + k)*C + lane*R + q, so one
 // wave-instruction reads 64*R consecutive values (R=2: 16 B per lane, 1 KiB per wave --
-// the widest coalesced access) and each lane owns R consecutive rows.
+// the widest coalesced access); lane l owns rows l and l + 64 of the slice, so each x
+// gather of a wave touches the columns of 64 consecutive rows (half the cache lines of
+// an adjacent-row pairing) and y is stored as R coalesced 512-byte rows.
 //
 // One workgroup = 4 waves = 4 slices; blockIdx.y picks the RowOp (block row).  All RowOp
 // fields are wave-uniform and come in through scalar loads.
@@ -170,7 +172,7 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const Bases &bases)
         w = op.slice_off[s + 1] - off0;
     }
     const size_t base = (size_t)off0 * C + (size_t)lane * R;
-    const int r0 = s * C + lane * R;
+    const int r0 = s * C + lane;   // row of q is r0 + 64 * q
     const int nrows = op.nrows;
 
     // epilogue operands first: their latency overlaps the matrix stream
@@ -191,7 +193,7 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const Bases &bases)
     }
 #pragma unroll
     for (int q = 0; q < R; ++q) {
-        const int r = r0 + q;
+        const int r = r0 + 64 * q;
         const bool in = r < nrows;
         masked[q] = in && op.rowmask != nullptr && op.rowmask[r] != 0;
         e0[q] = (in && pa) ? pa[r] : 0.0;
@@ -241,23 +243,14 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const Bases &bases)
             }
         }
     }
-    if constexpr (R == 2) {
-        if (r0 + 1 < nrows) {
-            d2u o;
-            o.x = out[0];
-            o.y = out[1];
-            *reinterpret_cast<d2u *>(y + r0) = o;
-        } else if (r0 < nrows) {
-            y[r0] = out[0];
-        }
-    } else {
-        if (r0 < nrows) y[r0] = out[0];
-    }
+#pragma unroll
+    for (int q = 0; q < R; ++q)
+        if (r0 + 64 * q < nrows) y[r0 + 64 * q] = out[q];
     if (lin && op.y2.base >= 0) {
         double *__restrict__ y2 = const_cast<double *>(resolve(op.y2, bases));
 #pragma unroll
         for (int q = 0; q < R; ++q)
-            if (r0 + q < nrows) y2[r0 + q] = out2[q];
+            if (r0 + 64 * q < nrows) y2[r0 + 64 * q] = out2[q];
     }
 }
 
@@ -370,7 +363,8 @@ __global__ void extract_dinv_kernel(const int32_t *__restrict__ col,
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrows) return;
     const int s = r / C;
-    const int within = r - s * C;
+    const int rin = r - s * C;
+    const int within = (rin % 64) * R + rin / 64;
     const int off0 = slice_off[s];
     const int w = slice_off[s + 1] - off0;
     double d = 1.0;

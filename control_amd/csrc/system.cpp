@@ -171,7 +171,7 @@ int System::find_or_add_pattern(int64_t nrows, int64_t ncols, const int32_t *ind
     for (int s = 0; s < P.nslices; ++s) {
         const int w = off[s + 1] - off[s];
         for (int within = 0; within < C; ++within) {
-            const int64_t r = (int64_t)s * C + within;
+            const int64_t r = (int64_t)s * C + (within % P.R) * 64 + within / P.R;   // lane-major
             const int32_t self = (int32_t)std::min<int64_t>(std::min<int64_t>(r, nrows - 1),
                                                             ncols - 1);
             const int len = r < nrows ? indptr[r + 1] - indptr[r] : 0;
