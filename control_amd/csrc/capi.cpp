@@ -177,6 +177,7 @@ int kkt_pc_apply(kkt_handle h, const double *x, double *y) {
         up(S, dx.p, x);
         S.pc_apply(dx.p, dy.p);
         down(S, dy.p, y);
+        if (S.pc) S.pc->check();
         if (S.pc_cb_failed) {
             S.pc_cb_failed = false;
             fail(KKT_ERR_CALLBACK, "Error encountered in preconditioner callback");

@@ -11,11 +11,23 @@ typedef int i2 __attribute__((ext_vector_type(2)));
 // vector blocks start at multiples of nx doubles: only 8-byte alignment is guaranteed
 typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 
-__device__ __forceinline__ const double *resolve(const VRef &r, const Bases &B) {
+// Pointers that arrive inside RowOp descriptors (loaded from memory) are generic to the
+// compiler, which then emits flat_load/flat_store: those count on vmcnt AND lgkmcnt and
+// force full `s_waitcnt vmcnt(0) lgkmcnt(0)` drains, and are not a valid hand-off form
+// (Guideline 16).  Everything here is hipMalloc memory: cast to the global address space.
+#define KKT_GLOBAL __attribute__((address_space(1)))
+typedef KKT_GLOBAL const double *gcd_p;
+typedef KKT_GLOBAL double *gd_p;
+typedef KKT_GLOBAL const int32_t *gci_p;
+typedef KKT_GLOBAL const uint8_t *gcb_p;
+typedef KKT_GLOBAL const d2 *gcd2_p;
+typedef KKT_GLOBAL const i2 *gci2_p;
+
+__device__ __forceinline__ gcd_p resolve(const VRef &r, const Bases &B) {
     if (r.base < 0) return nullptr;
-    if (r.base == 0) return reinterpret_cast<const double *>(r.off);
+    if (r.base == 0) return (gcd_p) reinterpret_cast<const double *>(r.off);
     const double *p = r.base == 1 ? B.p[0] : r.base == 2 ? B.p[1] : r.base == 3 ? B.p[2] : B.p[3];
-    return p + r.off;
+    return (gcd_p)(p + r.off);
 }
 
 // ---------------------------------------------------------------- fused block-row SpMV
@@ -42,14 +54,40 @@ __device__ __forceinline__ const double *resolve(const VRef &r, const Bases &B) 
 // then all of its x gathers, are in flight together: small launches (one 66k-row block in
 // the preconditioner sweeps) are latency-bound and this removes dependent round trips.
 
+// COH = true (persistent row programs): vector operands are exchanged between workgroups
+// inside one launch, so every vector load is an agent-scope relaxed atomic load
+// (global_load ... sc1: bypasses this CU's L1, served by L2) and every vector store an
+// agent-scope relaxed atomic store (write-through) -- the R1 hand-off form of
+// cdna_hip_programming.md Guideline 16 that needs no acquire fence.
+template <bool COH>
+__device__ __forceinline__ double ldv(gcd_p p) {
+    if constexpr (COH) {
+        const unsigned long long u = __hip_atomic_load(
+            (KKT_GLOBAL unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __longlong_as_double((long long)u);
+    } else {
+        return *p;
+    }
+}
+template <bool COH>
+__device__ __forceinline__ void stv(gd_p p, double v) {
+    if constexpr (COH) {
+        __hip_atomic_store((KKT_GLOBAL unsigned long long *)p,
+                           (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *p = v;
+    }
+}
+
 template <int R, bool NT>
-__device__ __forceinline__ void load_vals(const double *__restrict__ p, double (&v)[R]) {
+__device__ __forceinline__ void load_vals(gcd_p p, double (&v)[R]) {
     if constexpr (R == 2) {
         d2 t;
         if constexpr (NT)
-            t = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(p));
+            t = __builtin_nontemporal_load((gcd2_p)p);
         else
-            t = *reinterpret_cast<const d2 *>(p);
+            t = *(gcd2_p)p;
         v[0] = t.x;
         v[1] = t.y;
     } else {
@@ -61,9 +99,9 @@ __device__ __forceinline__ void load_vals(const double *__restrict__ p, double (
 }
 
 template <int R>
-__device__ __forceinline__ void load_cols(const int32_t *__restrict__ p, int (&c)[R]) {
+__device__ __forceinline__ void load_cols(gci_p p, int (&c)[R]) {
     if constexpr (R == 2) {
-        const i2 t = *reinterpret_cast<const i2 *>(p);
+        const i2 t = *(gci2_p)p;
         c[0] = t.x;
         c[1] = t.y;
     } else {
@@ -71,27 +109,27 @@ __device__ __forceinline__ void load_cols(const int32_t *__restrict__ p, int (&c
     }
 }
 
-template <int R, bool NT, int W>
+template <int R, bool NT, int W, bool COH>
 __device__ __forceinline__ void accumulate_exact(const RowOp &op, const Bases &bases,
                                                  size_t base, double (&acc)[R]) {
     constexpr int C = 64 * R;
     constexpr int CH = 8;                       // slots per register chunk
     constexpr int NCH = (W + CH - 1) / CH;
-    const int32_t *__restrict__ colp = op.col + base;
+    const gci_p colp = (gci_p)op.col + base;
     int c[W][R];
 #pragma unroll
     for (int k = 0; k < W; ++k) load_cols<R>(colp + (size_t)k * C, c[k]);
     const int nterms = op.nterms;
     double vn[CH][R];                           // values of the next (term, chunk)
     {
-        const double *__restrict__ vp = op.t[0].vals + base;
+        const gcd_p vp = (gcd_p)op.t[0].vals + base;
 #pragma unroll
         for (int k = 0; k < (W < CH ? W : CH); ++k) load_vals<R, NT>(vp + (size_t)k * C, vn[k]);
     }
     for (int t = 0; t < nterms; ++t) {
-        const double *__restrict__ x = resolve(op.t[t].x, bases);
-        const double *__restrict__ vcur = op.t[t].vals + base;
-        const double *__restrict__ vnext = (t + 1 < nterms) ? op.t[t + 1].vals + base : vcur;
+        const gcd_p x = resolve(op.t[t].x, bases);
+        const gcd_p vcur = (gcd_p)op.t[t].vals + base;
+        const gcd_p vnext = (t + 1 < nterms) ? (gcd_p)op.t[t + 1].vals + base : vcur;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             constexpr int dummy = 0;
@@ -105,7 +143,7 @@ __device__ __forceinline__ void accumulate_exact(const RowOp &op, const Bases &b
 #pragma unroll
                     for (int q = 0; q < R; ++q) {
                         v[k][q] = vn[k][q];
-                        xv[k][q] = x[c[k0 + k][q]];
+                        xv[k][q] = ldv<COH>(x + c[k0 + k][q]);
                     }
                 }
             // next chunk's (or next term's first chunk's) values go in flight now
@@ -130,15 +168,15 @@ __device__ __forceinline__ void accumulate_exact(const RowOp &op, const Bases &b
     }
 }
 
-template <int R, bool NT>
+template <int R, bool NT, bool COH>
 __device__ __forceinline__ void accumulate_generic(const RowOp &op, const Bases &bases,
                                                    size_t base, int w, double (&acc)[R]) {
     constexpr int C = 64 * R;
-    const int32_t *__restrict__ colp = op.col + base;
+    const gci_p colp = (gci_p)op.col + base;
     const int nterms = op.nterms;
     for (int t = 0; t < nterms; ++t) {
-        const double *__restrict__ vp = op.t[t].vals + base;
-        const double *__restrict__ x = resolve(op.t[t].x, bases);
+        const gcd_p vp = (gcd_p)op.t[t].vals + base;
+        const gcd_p x = resolve(op.t[t].x, bases);
 #pragma unroll 4
         for (int k = 0; k < w; ++k) {
             int c[R];
@@ -146,18 +184,16 @@ __device__ __forceinline__ void accumulate_generic(const RowOp &op, const Bases 
             load_cols<R>(colp + (size_t)k * C, c);
             load_vals<R, NT>(vp + (size_t)k * C, v);
 #pragma unroll
-            for (int q = 0; q < R; ++q) acc[q] = __builtin_fma(v[q], x[c[q]], acc[q]);
+            for (int q = 0; q < R; ++q) acc[q] = __builtin_fma(v[q], ldv<COH>(x + c[q]), acc[q]);
         }
     }
 }
 
 // WFIX > 0: the launcher knows every slice of every RowOp in the launch has width WFIX
 // (structured meshes: 7 for 2-D P1, 15 for 3-D P1) and picks the kernel unrolled for it.
-template <int R, bool NT, int WFIX>
-__device__ __forceinline__ void rowops_body(const RowOp &op, const Bases &bases) {
-    const int wave = threadIdx.x >> 6;
+template <int R, bool NT, int WFIX, bool COH>
+__device__ __forceinline__ void rowops_body(const RowOp &op, const Bases &bases, const int s) {
     const int lane = threadIdx.x & 63;
-    const int s = blockIdx.x * 4 + wave;
     if (s >= op.nslices) return;
     constexpr int C = 64 * R;
     int off0, w;
@@ -168,8 +204,8 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const Bases &bases)
         w = op.uniform_w;
         off0 = s * w;
     } else {
-        off0 = op.slice_off[s];
-        w = op.slice_off[s + 1] - off0;
+        off0 = ((gci_p)op.slice_off)[s];
+        w = ((gci_p)op.slice_off)[s + 1] - off0;
     }
     const size_t base = (size_t)off0 * C + (size_t)lane * R;
     const int r0 = s * C + lane;   // row of q is r0 + 64 * q
@@ -179,27 +215,28 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const Bases &bases)
     double e0[R], e1[R], e2[R], e3[R];
     bool masked[R];
     const bool lin = op.mode == EPI_LIN;
-    const double *pa, *pb, *pc, *pd;
+    gcd_p pa, pb, pc, pd;
+    const gcb_p rowmask = (gcb_p)op.rowmask;
     if (lin) {
         pa = resolve(op.yin, bases);
         pb = resolve(op.z, bases);
         pc = resolve(op.mx, bases);
-        pd = op.y2.base >= 0 ? op.dinv : nullptr;
+        pd = op.y2.base >= 0 ? (gcd_p)op.dinv : nullptr;
     } else {
         pa = resolve(op.pkm1, bases);
         pb = resolve(op.pk, bases);
         pc = resolve(op.b, bases);
-        pd = op.dinv;
+        pd = (gcd_p)op.dinv;
     }
 #pragma unroll
     for (int q = 0; q < R; ++q) {
         const int r = r0 + 64 * q;
         const bool in = r < nrows;
-        masked[q] = in && op.rowmask != nullptr && op.rowmask[r] != 0;
-        e0[q] = (in && pa) ? pa[r] : 0.0;
-        e1[q] = (in && pb) ? pb[r] : 0.0;
-        e2[q] = (in && pc) ? pc[r] : 0.0;
-        e3[q] = (in && pd) ? pd[r] : 0.0;
+        masked[q] = in && rowmask != nullptr && rowmask[r] != 0;
+        e0[q] = (in && pa) ? ldv<COH>(pa + r) : 0.0;
+        e1[q] = (in && pb) ? ldv<COH>(pb + r) : 0.0;
+        e2[q] = (in && pc) ? ldv<COH>(pc + r) : 0.0;
+        e3[q] = (in && pd) ? pd[r] : 0.0;   // dinv: never written inside a launch
     }
 
     double acc[R];
@@ -207,12 +244,12 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const Bases &bases)
     for (int q = 0; q < R; ++q) acc[q] = 0.0;
     if (op.nterms > 0) {
         if constexpr (WFIX > 0)
-            accumulate_exact<R, NT, WFIX>(op, bases, base, acc);
+            accumulate_exact<R, NT, WFIX, COH>(op, bases, base, acc);
         else
-            accumulate_generic<R, NT>(op, bases, base, w, acc);
+            accumulate_generic<R, NT, COH>(op, bases, base, w, acc);
     }
 
-    double *__restrict__ y = const_cast<double *>(resolve(op.y, bases));
+    const gd_p y = (gd_p)resolve(op.y, bases);
     double out[R], out2[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) {
@@ -245,12 +282,12 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const Bases &bases)
     }
 #pragma unroll
     for (int q = 0; q < R; ++q)
-        if (r0 + 64 * q < nrows) y[r0 + 64 * q] = out[q];
+        if (r0 + 64 * q < nrows) stv<COH>(y + r0 + 64 * q, out[q]);
     if (lin && op.y2.base >= 0) {
-        double *__restrict__ y2 = const_cast<double *>(resolve(op.y2, bases));
+        const gd_p y2 = (gd_p)resolve(op.y2, bases);
 #pragma unroll
         for (int q = 0; q < R; ++q)
-            if (r0 + 64 * q < nrows) y2[r0 + 64 * q] = out2[q];
+            if (r0 + 64 * q < nrows) stv<COH>(y2 + r0 + 64 * q, out2[q]);
     }
 }
 
@@ -259,18 +296,112 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const Bases &bases)
 template <int R, int WFIX>
 __global__ __launch_bounds__(256) void kkt_spmv_rows(const RowOp *__restrict__ ops,
                                                      const Bases bases) {
-    rowops_body<R, true, WFIX>(ops[blockIdx.y], bases);
+    rowops_body<R, true, WFIX, false>(ops[blockIdx.y], bases, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 template <int R, int WFIX>
 __global__ __launch_bounds__(256) void pc_rows(const RowOp *__restrict__ ops,
                                                const Bases bases) {
-    rowops_body<R, false, WFIX>(ops[blockIdx.y], bases);
+    rowops_body<R, false, WFIX, false>(ops[blockIdx.y], bases, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 // One RowOp passed by value: the descriptor arrives with the kernel arguments instead of
 // through a dependent load -- one round trip less on the latency-bound sweep steps.
 template <int R, int WFIX>
 __global__ __launch_bounds__(256) void pc_row_step(const RowOp op, const Bases bases) {
-    rowops_body<R, false, WFIX>(op, bases);
+    rowops_body<R, false, WFIX, false>(op, bases, blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+
+
+// ---------------------------------------------------------------- persistent row program
+//
+// The time sweeps of the block-Schur preconditioner are chains of dependent single-block
+// steps (2 n_t solves x schur_its Chebyshev steps); as separate launches each costs ~5 us
+// of kernel boundary + cold dependent loads.  Here ONE launch walks the whole chain:
+// workgroup j owns the same slices in every phase, and before phase ph it waits only for
+// the workgroups whose rows it gathers from (and that gather from it) to have finished
+// phase ph-1 -- a neighbour barrier through per-workgroup phase counters, not a grid
+// barrier.  Hand-off form: sc1 payload stores, every wave drains (vmcnt(0)), workgroup
+// barrier, one lane publishes the counter; consumer: one wave polls relaxed, workgroup
+// barrier, then sc1 loads only (Guideline 16, R1 with sc1 loads in place of the acquire).
+// Correctness does not depend on placement; residency does: the grid is at most one
+// workgroup per CU.  Every spin is bounded: on a time-out the error word is set and the
+// kernel runs to its end (results invalid, reported by the host) instead of hanging.
+constexpr int FLAG_STRIDE = 32;                 // one 128-byte line per workgroup counter
+constexpr unsigned PROG_SPIN_LIMIT = 1u << 22;
+
+template <int R, int WFIX>
+__global__ __launch_bounds__(512) void pc_row_program(const RowOp *__restrict__ ops, int nphases,
+                                                       const int2 *__restrict__ dep,
+                                                       unsigned *flags, unsigned *err) {
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wpw = blockDim.x >> 6;
+    const int j = blockIdx.x;
+    const int s = j * wpw + wave;
+    const int2 d = dep[j];
+    const Bases B{{nullptr, nullptr, nullptr, nullptr}};
+    for (int ph = 0; ph < nphases; ++ph) {
+        if (ph > 0) {
+            if (wave == 0) {
+                const int jj = d.x + lane;
+                unsigned spins = 0;
+                bool ok;
+                do {
+                    ok = jj > d.y || __hip_atomic_load(flags + (size_t)jj * FLAG_STRIDE,
+                                                       __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)ph;
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                } while (++spins < PROG_SPIN_LIMIT);
+                if (!__all(ok) && lane == 0) atomicOr(err, 1u);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __syncthreads();
+        }
+        rowops_body<R, false, WFIX, true>(ops[ph], B, s);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_store(flags + (size_t)j * FLAG_STRIDE, (unsigned)(ph + 1), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+int prog_flag_words(int nwg) { return nwg * FLAG_STRIDE; }
+
+typedef void (*prog_fn)(const RowOp *, int, const int2 *, unsigned *, unsigned *);
+static prog_fn pick_program(int R, int uniform_w) {
+    if (R != 2) return pc_row_program<1, 0>;
+    switch (uniform_w) {
+#define KKT_W(n) case n: return pc_row_program<2, n>;
+        KKT_W(1) KKT_W(2) KKT_W(3) KKT_W(4) KKT_W(5) KKT_W(6) KKT_W(7) KKT_W(8)
+        KKT_W(9) KKT_W(10) KKT_W(11) KKT_W(12) KKT_W(13) KKT_W(14) KKT_W(15) KKT_W(16)
+#undef KKT_W
+        default: return pc_row_program<2, 0>;
+    }
+}
+
+// Workgroups of 64*waves_per_wg threads that are certainly co-resident on this device
+// (occupancy query of the chosen instantiation, at most 4 per CU: MI355X_MICROARCH.md,
+// residency and cooperative launch).
+int row_program_max_wgs(int R, int uniform_w, int waves_per_wg) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_program(R, uniform_w),
+                                                     64 * waves_per_wg, 0) != hipSuccess)
+        return 0;
+    if (per_cu > 4) per_cu = 4;
+    return cus * per_cu;
+}
+
+void launch_row_program(hipStream_t s, const RowOp *d_ops, int nphases, int nwg, int waves_per_wg,
+                        int R, int uniform_w, const int32_t *d_dep, unsigned *d_flags,
+                        unsigned *d_err) {
+    if (nphases <= 0 || nwg <= 0) return;
+    (void)hipMemsetAsync(d_flags, 0, (size_t)prog_flag_words(nwg) * sizeof(unsigned), s);
+    const dim3 grid(nwg), block(64 * waves_per_wg);
+    hipLaunchKernelGGL(pick_program(R, uniform_w), grid, block, 0, s, d_ops, nphases,
+                       reinterpret_cast<const int2 *>(d_dep), d_flags, d_err);
 }
 
 template <int R, int WFIX>

@@ -56,6 +56,14 @@ void launch_rowops(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, 
                    const Bases &bases, int tag, int uniform_w,
                    const RowOp *h_single = nullptr);
 
+// One persistent launch that runs `nphases` single-block RowOps in order, workgroup j
+// waiting before each phase for the workgroups d_dep[2j] .. d_dep[2j+1] (kernels.hip).
+int prog_flag_words(int nwg);
+int row_program_max_wgs(int R, int uniform_w, int waves_per_wg);
+void launch_row_program(hipStream_t s, const RowOp *d_ops, int nphases, int nwg, int waves_per_wg,
+                        int R, int uniform_w, const int32_t *d_dep, unsigned *d_flags,
+                        unsigned *d_err);
+
 // ---- value-array preparation
 void launch_csr_to_sell(hipStream_t s, const double *csr_vals, const int32_t *sell2csr,
                         double *sell_vals, int64_t n_padded);

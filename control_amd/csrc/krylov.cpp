@@ -322,6 +322,7 @@ void System::solve(const double *d_b, double *d_u, int *its_out, int *reason_out
     // corrected solution (preconditioner.py:761-766)
     ns_project(d_u, d_u);
     sync();
+    if (pc) pc->check();
     info.last_solve_ms =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     if (its_out) *its_out = its;

@@ -1,5 +1,6 @@
 #include "pc.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -41,6 +42,8 @@ SchurPC::SchurPC(System &S, const kkt_pc_desc &d) : S_(S), d_(d) {
     d_.bc_idx = nullptr;
     const char *e = std::getenv("KKT_NO_GRAPH");
     use_graph_ = !(e && e[0] == '1');
+    e = std::getenv("KKT_PERSISTENT");
+    use_programs_ = !(e && e[0] == '0');
     build();
 }
 
@@ -57,7 +60,8 @@ void SchurPC::clear_program() {
     }
     segments_.clear();
     for (auto &s : steps_)
-        if (s.kind == PcStep::ROWS && s.rows.d_ops) (void)hipFree(s.rows.d_ops);
+        if ((s.kind == PcStep::ROWS || s.kind == PcStep::PROG) && s.rows.d_ops)
+            (void)hipFree(s.rows.d_ops);
     steps_.clear();
 }
 
@@ -75,6 +79,102 @@ void SchurPC::values_changed() {
         build_BE();
     else
         build_CN();
+    fuse_programs();
+}
+
+// Replace every run of >= 4 consecutive single-block steps (the time sweeps) by one
+// persistent launch with neighbour synchronisation (kernels.hip, pc_row_program).
+void SchurPC::fuse_programs() {
+    if (!use_programs_) return;
+    const Pattern &P = S_.patterns[m_pat_];
+    if (!d_dep_) {
+        int wpw = 0, nwg = 0;
+        for (int cand : {4, 8}) {
+            const int n = (P.nslices + cand - 1) / cand;
+            if (n <= row_program_max_wgs(P.R, P.uniform_w, cand)) {
+                wpw = cand;
+                nwg = n;
+                break;
+            }
+        }
+        if (!wpw) {
+            use_programs_ = false;
+            return;
+        }
+        // workgroup j must wait for every workgroup whose rows it gathers from, and for
+        // every workgroup that gathers from its rows (write-after-read on rotating buffers)
+        const int64_t rpw = (int64_t)wpw * 64 * P.R;
+        std::vector<int32_t> lo(nwg), hi(nwg);
+        for (int j = 0; j < nwg; ++j) {
+            int64_t cmin = j * rpw, cmax = j * rpw;
+            const int64_t r1 = std::min<int64_t>(P.nrows, (j + 1) * rpw);
+            for (int64_t r = j * rpw; r < r1; ++r)
+                if (P.h_indptr[r + 1] > P.h_indptr[r]) {
+                    cmin = std::min<int64_t>(cmin, P.h_indices[P.h_indptr[r]]);
+                    cmax = std::max<int64_t>(cmax, P.h_indices[P.h_indptr[r + 1] - 1]);
+                }
+            lo[j] = (int32_t)(cmin / rpw);
+            hi[j] = (int32_t)std::min<int64_t>(nwg - 1, cmax / rpw);
+        }
+        std::vector<int32_t> slo = lo, shi = hi;
+        for (int j = 0; j < nwg; ++j)
+            for (int k = lo[j]; k <= hi[j]; ++k) {
+                slo[k] = std::min(slo[k], (int32_t)j);
+                shi[k] = std::max(shi[k], (int32_t)j);
+            }
+        std::vector<int32_t> dep(2 * (size_t)nwg);
+        for (int j = 0; j < nwg; ++j) {
+            if (shi[j] - slo[j] + 1 > 64) {   // one polling wave covers at most 64 neighbours
+                use_programs_ = false;
+                return;
+            }
+            dep[2 * j] = slo[j];
+            dep[2 * j + 1] = shi[j];
+        }
+        prog_wpw_ = wpw;
+        prog_nwg_ = nwg;
+        d_dep_ = dev_upload(dep.data(), dep.size());
+        d_flags_ = dev_alloc<unsigned>(prog_flag_words(nwg));
+        d_err_ = dev_alloc<unsigned>(1);
+        HIPCHK(hipMemset(d_err_, 0, sizeof(unsigned)));
+        owned_.push_back(d_dep_);
+        owned_.push_back(d_flags_);
+        owned_.push_back(d_err_);
+    }
+    std::vector<PcStep> out;
+    size_t k = 0;
+    while (k < steps_.size()) {
+        size_t e = k;
+        while (e < steps_.size() && steps_[e].kind == PcStep::ROWS && steps_[e].rows.nops == 1) ++e;
+        if (e - k >= 4) {
+            std::vector<RowOp> ops;
+            for (size_t q = k; q < e; ++q) {
+                ops.push_back(steps_[q].rows.h_op);
+                (void)hipFree(steps_[q].rows.d_ops);
+            }
+            PcStep s;
+            s.kind = PcStep::PROG;
+            s.rows.d_ops = dev_upload(ops.data(), ops.size());
+            s.nphases = (int)ops.size();
+            out.push_back(s);
+            k = e;
+        } else {
+            for (size_t q = k; q < std::max(e, k + 1); ++q) out.push_back(steps_[q]);
+            k = std::max(e, k + 1);
+        }
+    }
+    steps_.swap(out);
+}
+
+void SchurPC::check() {
+    if (!d_err_) return;
+    unsigned e = 0;
+    HIPCHK(hipMemcpyAsync(&e, d_err_, sizeof e, hipMemcpyDeviceToHost, S_.stream));
+    HIPCHK(hipStreamSynchronize(S_.stream));
+    if (e) {
+        HIPCHK(hipMemset(d_err_, 0, sizeof(unsigned)));
+        fail(KKT_ERR_HIP, "persistent sweep kernel timed out waiting for a neighbour workgroup");
+    }
 }
 
 const double *SchurPC::block_vals(int q, int i, int j) const {
@@ -163,8 +263,8 @@ void SchurPC::push_rows(std::vector<RowOp> &r) {
         const char *e = std::getenv("KKT_KERNARG_OPS");
         return e && e[0] == '1';
     }();
-    if (r.size() == 1 && kernarg_ops) {
-        s.rows.single = true;
+    if (r.size() == 1) {
+        s.rows.single = kernarg_ops;
         s.rows.h_op = r[0];
     }
     steps_.push_back(s);
@@ -527,6 +627,12 @@ void SchurPC::replay(size_t first, size_t last) {
             case PcStep::COPY:
                 launch_copy(st, s.y, s.x, s.nx);
                 break;
+            case PcStep::PROG: {
+                const Pattern &P = S_.patterns[m_pat_];
+                launch_row_program(st, s.rows.d_ops, s.nphases, prog_nwg_, prog_wpw_, P.R,
+                                   P.uniform_w, d_dep_, d_flags_, d_err_);
+                break;
+            }
             case PcStep::COMM:
                 if (!S_.comm) fail(KKT_ERR_STATE, "time-sharded system without a transport");
                 S_.comm->sendrecv(s.x, s.nx, s.dst, s.y, s.nx, s.src, st);

@@ -11,7 +11,7 @@
 namespace kkt {
 
 struct PcStep {
-    enum Kind { ROWS, TIME, COPY, COMM } kind;
+    enum Kind { ROWS, TIME, COPY, COMM, PROG } kind;
     RowLaunch rows;                 // ROWS
     double *y = nullptr;            // TIME / COPY
     const double *x = nullptr;
@@ -19,6 +19,7 @@ struct PcStep {
     int64_t nx = 0;                 // TIME: block length; COPY / COMM: element count
     const double *lo_halo = nullptr, *hi_halo = nullptr;   // TIME on a time shard
     int dst = -1, src = -1;         // COMM: send x to dst, receive y from src
+    int nphases = 0;                // PROG: rows.d_ops holds nphases single-block RowOps
 };
 
 class SchurPC {
@@ -30,6 +31,7 @@ class SchurPC {
     double *in() { return in_; }
     double *out() { return out_; }
     void values_changed();
+    void check();   // throws if a persistent row program reported a time-out
     int bc_set() const { return bc_set_; }
     int64_t n_launches() const { return (int64_t)steps_.size(); }
 
@@ -66,6 +68,12 @@ class SchurPC {
     };
     std::vector<Segment> segments_;
     bool use_graph_ = true;
+    // persistent row programs (kernels.hip, pc_row_program)
+    bool use_programs_ = true;
+    int prog_wpw_ = 0, prog_nwg_ = 0;
+    int32_t *d_dep_ = nullptr;
+    unsigned *d_flags_ = nullptr, *d_err_ = nullptr;
+    void fuse_programs();
 
     struct Term {
         const double *vals;

@@ -54,6 +54,27 @@ def test_preconditioner_parity(CN):
     assert np.array_equal(G[:, nodes], X[:, nodes])
 
 
+@pytest.mark.parametrize("CN", [False, True])
+def test_preconditioner_parity_many_workgroups(CN):
+    """96x96 mesh: 9409 rows = 74 slices = 19 workgroups, so the persistent sweep program
+    (pc_row_program) really synchronises neighbours; also run with it disabled."""
+    import os
+    p = common.heat_problem(n=96, n_t=6, CN=CN)
+    osys = common.oracle_system(p)
+    schur = (6, 0.05, 2.1)
+    x = common.rng_vector(osys.N)
+    ref = osys.pc_apply(common.oracle_pc(p, MASS, schur), x)
+    got = common.gpu_system(p).pc_apply(x, common.gpu_pc(p, MASS, schur))
+    assert common.rel_err(got, ref) < 1e-10
+    os.environ["KKT_PERSISTENT"] = "0"
+    try:
+        got2 = common.gpu_system(p).pc_apply(x, common.gpu_pc(p, MASS, schur))
+    finally:
+        del os.environ["KKT_PERSISTENT"]
+    # same arithmetic in the same order: launches and the persistent program agree exactly
+    assert np.array_equal(got, got2)
+
+
 KRYLOV_SCHUR = (12, 0.08, 2.1)   # beta = 1e-2 on the 10x10 mesh: kappa(D^-1 S) ~ 25
 
 
