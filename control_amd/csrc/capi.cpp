@@ -264,6 +264,15 @@ int kkt_get_info(kkt_handle h, kkt_info *info) {
     });
 }
 
+// diagnostic builds only (make EXTRA=-DKKT_STAMPS): per-workgroup cycle sums of the
+// persistent row program; not part of include/kkt.h
+int kkt_debug_prog_stats(kkt_handle h, unsigned long long *out, int n) {
+    KKT_TRY(h, {
+        if (!S.pc) fail(KKT_ERR_STATE, "no built-in preconditioner");
+        S.pc->debug_read(out, n);
+    });
+}
+
 // ---- multi-GPU transport
 int kkt_comm_unique_id(void *id_out_128) {
     if (!id_out_128) return KKT_ERR_ARG;

@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 namespace kkt {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -364,6 +366,346 @@ __global__ __launch_bounds__(512) void pc_row_program(const RowOp *__restrict__ 
             __hip_atomic_store(flags + (size_t)j * FLAG_STRIDE, (unsigned)(ph + 1), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// ---- persistent row program, data-flow form ("the data is the flag", Guideline 16 R2)
+//
+// Every vector element that crosses workgroups inside the program travels as two 8-byte
+// granules {tag = phase epoch, 32 value bits}, each written by ONE aligned 8-byte
+// agent-scope store; a gather re-reads its granules until every tag carries the epoch of
+// the producing phase.  No flag, no drain (s_waitcnt vmcnt(0)), no poll wave: a hand-off
+// costs one store -> visible -> load latency.  Two granule buffers alternate between
+// phases.  Write-after-read: a workgroup stores its phase-ph granules only after its own
+// barrier of phase ph, which follows its gathers; whoever observes one of those granules
+// therefore knows that workgroup has finished reading generation ph-1, and overwrites the
+// buffer holding it (the alternate one) only after observing them -- which needs the
+// gather relation between workgroups to be symmetric (checked on the host).
+typedef KKT_GLOBAL unsigned long long *gu64_p;
+
+// A phase descriptor (one RowOp, < 512 bytes) is fetched by ONE wave-wide vector load --
+// lane l holds bytes 8l..8l+7 -- a whole phase ahead, and its fields are moved to scalar
+// registers with v_readlane.  Reading the descriptor field by field through the scalar
+// cache cost a dependent ~1 us miss per touched line and phase (scripts/prog_stamps.py).
+static_assert(sizeof(RowOp) <= 512, "RowOp must fit one 64 x 8-byte wave load");
+__device__ __forceinline__ unsigned long long rl64(unsigned long long v, int lane) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+#define KKT_D64(field) rl64(desc, (int)(offsetof(RowOp, field) / 8))
+#define KKT_DPTR(type, field) ((type)(uintptr_t)KKT_D64(field))
+#define KKT_DF64(field) __longlong_as_double((long long)KKT_D64(field))
+#define KKT_D32(field)                                                                   \
+    ((int)(unsigned)(rl64(desc, (int)(offsetof(RowOp, field) / 8)) >>                    \
+                     (8 * (offsetof(RowOp, field) % 8))))
+__device__ __forceinline__ gcd_p vref_ptr(long long off, int base) {
+    return base == 0 ? (gcd_p)(const double *)(uintptr_t)off : (gcd_p) nullptr;
+}
+
+// Register-resident state across phases.  A sweep is a chain of solves; inside one solve the
+// matrix, its Jacobi diagonal, the right-hand side row and the boundary mask do not change
+// and the Chebyshev operands p_k[r], p_{k-1}[r] are values this very thread produced one and
+// two phases earlier.  Re-loading any of them costs a ~1.2 us dependent round trip per phase
+// (measured, scripts/prog_stamps.py), so the kernel keeps a small pointer-keyed cache in
+// registers: a same-row operand whose address equals a cached one is taken from the cache
+// (bitwise the value in memory), and matrix values / column indices are re-loaded only when
+// their pointer changes.  What remains on the critical path of a Chebyshev phase is the
+// descriptor fetch and ONE gather round trip.
+template <int R, int W>
+__global__ __launch_bounds__(512) void pc_row_program_g(const RowOp *__restrict__ ops, int nphases,
+                                                         unsigned long long *g0,
+                                                         unsigned long long *g1, unsigned *err) {
+    constexpr int C = 64 * R;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * (blockDim.x >> 6) + wave;
+    const size_t base = (size_t)s * W * C + (size_t)lane * R;
+    const int r0 = s * C + lane;
+
+    // cache slots: 0 = y of ph-1, 1 = y2 of ph-1, 2 = gather output of ph-2, 3 = b, 4 = dinv
+    const void *kp0 = nullptr, *kp1 = nullptr, *kp2 = nullptr, *kp3 = nullptr, *kp4 = nullptr;
+    double kv0[R], kv1[R], kv2[R], kv3[R], kv4[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) kv0[q] = kv1[q] = kv2[q] = kv3[q] = kv4[q] = 0.0;
+    const void *cols_ptr = nullptr, *vals_ptr = nullptr, *mask_ptr = nullptr;
+    int c[W][R];
+    double v[W][R];
+    bool masked[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) masked[q] = false;
+
+#define KKT_FETCH(dst, ptr)                                                      \
+    do {                                                                         \
+        const void *key_ = (const void *)(const double *)(ptr);                  \
+        _Pragma("unroll") for (int q = 0; q < R; ++q) {                          \
+            const int r_ = r0 + 64 * q;                                          \
+            const bool in_ = active && r_ < nrows;                               \
+            double val_ = 0.0;                                                   \
+            if ((ptr) && in_) {                                                  \
+                if (key_ == kp0) val_ = kv0[q];                                  \
+                else if (key_ == kp1) val_ = kv1[q];                             \
+                else if (key_ == kp2) val_ = kv2[q];                             \
+                else if (key_ == kp3) val_ = kv3[q];                             \
+                else if (key_ == kp4) val_ = kv4[q];                             \
+                else val_ = (ptr)[r_];                                           \
+            }                                                                    \
+            dst[q] = val_;                                                       \
+        }                                                                        \
+    } while (0)
+
+#ifdef KKT_STAMPS
+    unsigned long long *sdbg = reinterpret_cast<unsigned long long *>(err + 64) + blockIdx.x * 16;
+    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#define KKT_STAGE(i)                                                       \
+    do {                                                                   \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();     \
+        if (threadIdx.x == 0) sdbg[8 + (i)] += t_now - t_prev;             \
+        t_prev = t_now;                                                    \
+    } while (0)
+#else
+#define KKT_STAGE(i)
+#endif
+    auto load_desc = [&](int ph) -> unsigned long long {
+        const KKT_GLOBAL unsigned long long *p =
+            (const KKT_GLOBAL unsigned long long *)(ops + ph);
+        return (size_t)lane * 8 < sizeof(RowOp) ? p[lane] : 0ull;
+    };
+    unsigned long long dnext = load_desc(0);
+    for (int ph = 0; ph < nphases; ++ph) {
+        const unsigned long long desc = dnext;
+        if (ph + 1 < nphases) dnext = load_desc(ph + 1);   // in flight during this phase
+        const int op_nslices = KKT_D32(nslices);
+        const int nrows = KKT_D32(nrows);
+        const int op_nterms = KKT_D32(nterms);
+        const bool lin = KKT_D32(mode) == EPI_LIN;
+        const bool active = s < op_nslices;
+        const int nterms = active ? op_nterms : 0;
+        KKT_STAGE(0);   // descriptor
+        const gu64_p xg = (gu64_p)((ph & 1) ? g0 : g1);   // written by phase ph-1
+        const gu64_p yg = (gu64_p)((ph & 1) ? g1 : g0);
+        const unsigned ep_in = (ph > 0 && op_nterms > 0) ? (unsigned)ph : 0u;
+        const unsigned ep_out = (unsigned)(ph + 1);
+        // program descriptors carry absolute pointers only (base 0) or null (base < 0)
+        const gcd_p p_y = vref_ptr((long long)KKT_D64(y.off), KKT_D32(y.base));
+        const gcd_p p_y2 = vref_ptr((long long)KKT_D64(y2.off), KKT_D32(y2.base));
+        const void *d_rowmask = KKT_DPTR(const void *, rowmask);
+        const void *d_col = KKT_DPTR(const void *, col);
+        const void *d_vals0 = KKT_DPTR(const void *, t[0].vals);
+        const gcd_p d_dinv = (gcd_p)KKT_DPTR(const double *, dinv);
+
+        // ---- operands of this thread's own rows (cache first)
+        gcd_p pa, pb, pc, pd;
+        if (lin) {
+            pa = vref_ptr((long long)KKT_D64(yin.off), KKT_D32(yin.base));
+            pb = vref_ptr((long long)KKT_D64(z.off), KKT_D32(z.base));
+            pc = vref_ptr((long long)KKT_D64(mx.off), KKT_D32(mx.base));
+            pd = p_y2 ? d_dinv : nullptr;
+        } else {
+            pa = vref_ptr((long long)KKT_D64(pkm1.off), KKT_D32(pkm1.base));
+            pb = vref_ptr((long long)KKT_D64(pk.off), KKT_D32(pk.base));
+            pc = vref_ptr((long long)KKT_D64(b.off), KKT_D32(b.base));
+            pd = d_dinv;
+        }
+        if (d_rowmask != mask_ptr) {
+            mask_ptr = d_rowmask;
+            const gcb_p rowmask = (gcb_p)(const uint8_t *)d_rowmask;
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int r = r0 + 64 * q;
+                masked[q] = active && r < nrows && rowmask != nullptr && rowmask[r] != 0;
+            }
+        }
+        double e0[R], e1[R], e2[R], e3[R];
+        KKT_FETCH(e0, pa);
+        KKT_FETCH(e1, pb);
+        KKT_FETCH(e2, pc);
+        KKT_FETCH(e3, pd);
+        // b (Chebyshev) and dinv stay the same through a solve: pin them
+        if (!lin) {
+            kp3 = (const void *)(const double *)pc;
+#pragma unroll
+            for (int q = 0; q < R; ++q) kv3[q] = e2[q];
+        }
+        if (pd) {
+            kp4 = (const void *)(const double *)pd;
+#pragma unroll
+            for (int q = 0; q < R; ++q) kv4[q] = e3[q];
+        }
+
+        KKT_STAGE(1);   // own-row operands (cache or memory)
+        // ---- matrix structure and values: re-load only when the pointer changes
+        double xv[W][R];
+        if (nterms > 0) {
+            if (d_col != cols_ptr) {
+                cols_ptr = d_col;
+                const gci_p colp = (gci_p)(const int32_t *)d_col + base;
+#pragma unroll
+                for (int k = 0; k < W; ++k) load_cols<R>(colp + (size_t)k * C, c[k]);
+            }
+            if (d_vals0 != vals_ptr) {
+                vals_ptr = d_vals0;
+                const gcd_p vp = (gcd_p)(const double *)d_vals0 + base;
+#pragma unroll
+                for (int k = 0; k < W; ++k) load_vals<R, false>(vp + (size_t)k * C, v[k]);
+            }
+            KKT_STAGE(2);   // index / matrix value loads (only when they change)
+            if (ep_in == 0) {   // produced before this launch: plain vector
+                const gcd_p x = vref_ptr((long long)KKT_D64(t[0].x.off), KKT_D32(t[0].x.base));
+#pragma unroll
+                for (int k = 0; k < W; ++k)
+#pragma unroll
+                    for (int q = 0; q < R; ++q) xv[k][q] = x[c[k][q]];
+            } else {
+                unsigned spins = 0;
+                bool ok;
+                do {
+                    ok = true;
+#pragma unroll
+                    for (int k = 0; k < W; ++k)
+#pragma unroll
+                        for (int q = 0; q < R; ++q) {
+                            const gu64_p g = xg + 2 * (size_t)c[k][q];
+                            const unsigned long long a =
+                                __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const unsigned long long b =
+                                __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok &= (unsigned)(a >> 32) == ep_in && (unsigned)(b >> 32) == ep_in;
+                            xv[k][q] = __longlong_as_double(
+                                (long long)((a & 0xffffffffull) | (b << 32)));
+                        }
+                    if (__all(ok)) break;
+                } while (++spins < PROG_SPIN_LIMIT);
+                if (!__all(ok) && lane == 0) atomicOr(err, 2u);
+            }
+        }
+        KKT_STAGE(3);   // gather
+        __syncthreads();   // this workgroup has finished reading generation ep_in
+        KKT_STAGE(4);   // barrier
+
+        double acc[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[q] = 0.0;
+        for (int t = 0; t < nterms; ++t) {
+            if (t > 0) {   // further terms of an update phase: values are not cached
+                vals_ptr = nullptr;
+                const gcd_p vp = (gcd_p)(const double *)(uintptr_t)rl64(
+                                     desc, (int)((offsetof(RowOp, t) + sizeof(SpmvTerm) * t +
+                                                  offsetof(SpmvTerm, vals)) / 8)) + base;
+#pragma unroll
+                for (int k = 0; k < W; ++k) load_vals<R, false>(vp + (size_t)k * C, v[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < W; ++k)
+#pragma unroll
+                for (int q = 0; q < R; ++q) acc[q] = __builtin_fma(v[k][q], xv[k][q], acc[q]);
+        }
+
+        const gd_p y = (gd_p)p_y;
+        const gd_p y2 = lin ? (gd_p)p_y2 : nullptr;
+        const double k_ca = KKT_DF64(ca), k_cy = KKT_DF64(cy), k_cz = KKT_DF64(cz);
+        const double k_malpha = KKT_DF64(malpha), k_c1 = KKT_DF64(c1), k_c2 = KKT_DF64(c2);
+        const double k_c3 = KKT_DF64(c3), k_post1 = KKT_DF64(post1), k_post2 = KKT_DF64(post2);
+        double outv[R], out2v[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int r = r0 + 64 * q;
+            double out = 0.0, out2 = 0.0;
+            if (lin) {
+                if (masked[q]) {
+                    out = pc ? k_malpha * e2[q] : 0.0;
+                } else {
+                    out = k_ca * acc[q];
+                    if (pa) out += k_cy * e0[q];
+                    if (pb) out += k_cz * e1[q];
+                }
+                out2 = k_c3 * (e3[q] * out);
+            } else if (!masked[q]) {
+                double t = pa ? k_c1 * e0[q] : 0.0;
+                if (pb) t += k_c2 * e1[q];
+                t += k_c3 * (e3[q] * (e2[q] - acc[q]));
+                out = k_post2 * (k_post1 * t);
+            }
+            outv[q] = out;
+            out2v[q] = out2;
+            if (active && r < nrows) {
+                y[r] = out;
+                if (y2) y2[r] = out2;
+                // the vector the next phase gathers: p_1 after a fused update, else y
+                const unsigned long long bits =
+                    (unsigned long long)__double_as_longlong(y2 ? out2 : out);
+                const unsigned long long tag = (unsigned long long)ep_out << 32;
+                __hip_atomic_store(yg + 2 * (size_t)r, tag | (bits & 0xffffffffull),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(yg + 2 * (size_t)r + 1, tag | (bits >> 32), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // rotate the cache: what was produced one phase ago becomes "two phases ago"
+#ifdef KKT_STAMPS
+        {
+            const unsigned long long t_now = __builtin_amdgcn_s_memtime();
+            if (threadIdx.x == 0) {
+                sdbg[8 + 5] += t_now - t_prev;   // fma + epilogue + store issue (no drain)
+                sdbg[2] += 1;
+            }
+            t_prev = t_now;
+        }
+        KKT_STAGE(6);   // store drain (diagnostic only)
+#endif
+        {
+            const bool had2 = kp1 != nullptr;
+            kp2 = had2 ? kp1 : kp0;
+#pragma unroll
+            for (int q = 0; q < R; ++q) kv2[q] = had2 ? kv1[q] : kv0[q];
+        }
+        kp0 = (const void *)(const double *)(gcd_p)y;
+        kp1 = y2 ? (const void *)(const double *)(gcd_p)y2 : nullptr;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            kv0[q] = outv[q];
+            kv1[q] = out2v[q];
+        }
+        // a fused update wrote the right-hand side of the solve that follows: pin it as b
+        if (lin && y2) {
+            kp3 = kp0;
+#pragma unroll
+            for (int q = 0; q < R; ++q) kv3[q] = outv[q];
+        }
+    }
+#undef KKT_FETCH
+#undef KKT_STAGE
+}
+
+typedef void (*progg_fn)(const RowOp *, int, unsigned long long *, unsigned long long *, unsigned *);
+static progg_fn pick_program_g(int uniform_w) {
+    switch (uniform_w) {
+#define KKT_W(n) case n: return pc_row_program_g<2, n>;
+        KKT_W(1) KKT_W(2) KKT_W(3) KKT_W(4) KKT_W(5) KKT_W(6) KKT_W(7) KKT_W(8)
+#undef KKT_W
+        default: return nullptr;   // wider rows: register pressure, use the counter form
+    }
+}
+bool row_program_g_available(int R, int uniform_w) { return R == 2 && pick_program_g(uniform_w); }
+int row_program_g_max_wgs(int uniform_w, int waves_per_wg) {
+    int dev = 0, cus = 0, per_cu = 0;
+    progg_fn f = pick_program_g(uniform_w);
+    if (!f || hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 64 * waves_per_wg, 0) != hipSuccess)
+        return 0;
+    if (per_cu > 4) per_cu = 4;
+    return cus * per_cu;
+}
+void launch_row_program_g(hipStream_t s, const RowOp *d_ops, int nphases, int nwg, int waves_per_wg,
+                          int uniform_w, unsigned long long *g0, unsigned long long *g1,
+                          size_t granule_words, unsigned *d_err) {
+    if (nphases <= 0 || nwg <= 0) return;
+    // tags of an earlier launch must not match this launch's epochs
+    (void)hipMemsetAsync(g0, 0, granule_words * sizeof(unsigned long long), s);
+    (void)hipMemsetAsync(g1, 0, granule_words * sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(pick_program_g(uniform_w), dim3(nwg), dim3(64 * waves_per_wg), 0, s, d_ops,
+                       nphases, g0, g1, d_err);
 }
 
 int prog_flag_words(int nwg) { return nwg * FLAG_STRIDE; }

@@ -59,6 +59,12 @@ void launch_rowops(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, 
 // One persistent launch that runs `nphases` single-block RowOps in order, workgroup j
 // waiting before each phase for the workgroups d_dep[2j] .. d_dep[2j+1] (kernels.hip).
 int prog_flag_words(int nwg);
+// data-flow form (tagged granules instead of phase counters), uniform widths 1..16 only
+bool row_program_g_available(int R, int uniform_w);
+int row_program_g_max_wgs(int uniform_w, int waves_per_wg);
+void launch_row_program_g(hipStream_t s, const RowOp *d_ops, int nphases, int nwg, int waves_per_wg,
+                          int uniform_w, unsigned long long *g0, unsigned long long *g1,
+                          size_t granule_words, unsigned *d_err);
 int row_program_max_wgs(int R, int uniform_w, int waves_per_wg);
 void launch_row_program(hipStream_t s, const RowOp *d_ops, int nphases, int nwg, int waves_per_wg,
                         int R, int uniform_w, const int32_t *d_dep, unsigned *d_flags,

@@ -89,9 +89,19 @@ void SchurPC::fuse_programs() {
     const Pattern &P = S_.patterns[m_pat_];
     if (!d_dep_) {
         int wpw = 0, nwg = 0;
-        for (int cand : {4, 8}) {
+        const char *pm0 = std::getenv("KKT_PROG_MODE");
+        const bool try_g = !(pm0 && pm0[0] == 'f') && row_program_g_available(P.R, P.uniform_w);
+        // data-flow form: one wave per workgroup (no workgroup barrier on the critical path)
+        // while all of them are co-resident; else 4 / 8 waves per workgroup
+        const char *pw = std::getenv("KKT_PROG_WAVES");
+        const int first = pw ? std::atoi(pw) : (try_g ? 1 : 4);
+        for (int cand : {first, 4, 8}) {
+            if (cand < 1 || cand > 8) continue;
             const int n = (P.nslices + cand - 1) / cand;
-            if (n <= row_program_max_wgs(P.R, P.uniform_w, cand)) {
+            const int cap = try_g ? std::min(row_program_g_max_wgs(P.uniform_w, cand),
+                                             row_program_max_wgs(P.R, P.uniform_w, cand))
+                                  : row_program_max_wgs(P.R, P.uniform_w, cand);
+            if (n <= cap) {
                 wpw = cand;
                 nwg = n;
                 break;
@@ -131,21 +141,65 @@ void SchurPC::fuse_programs() {
             dep[2 * j] = slo[j];
             dep[2 * j + 1] = shi[j];
         }
+        // data-flow form: needs the exact gather relation between workgroups to be symmetric
+        {
+            const char *pm = std::getenv("KKT_PROG_MODE");
+            bool want = !(pm && pm[0] == 'f') && row_program_g_available(P.R, P.uniform_w) &&
+                        nwg <= row_program_g_max_wgs(P.uniform_w, wpw);
+            if (want) {
+                std::vector<std::vector<int32_t>> reads(nwg);
+                for (int j = 0; j < nwg; ++j) {
+                    const int64_t r1 = std::min<int64_t>(P.nrows, (j + 1) * rpw);
+                    std::vector<char> seen(nwg, 0);
+                    for (int64_t r = j * rpw; r < r1; ++r)
+                        for (int32_t q = P.h_indptr[r]; q < P.h_indptr[r + 1]; ++q)
+                            seen[P.h_indices[q] / rpw] = 1;
+                    for (int k = 0; k < nwg; ++k)
+                        if (seen[k]) reads[j].push_back(k);
+                }
+                for (int j = 0; j < nwg && want; ++j)
+                    for (int32_t k : reads[j])
+                        if (!std::binary_search(reads[k].begin(), reads[k].end(), (int32_t)j))
+                            want = false;
+            }
+            prog_granule_ = want;
+            if (want) {
+                granule_words_ = 2 * (size_t)P.nslices * 64 * P.R;
+                d_g0_ = dev_alloc<unsigned long long>(granule_words_);
+                d_g1_ = dev_alloc<unsigned long long>(granule_words_);
+                owned_.push_back(d_g0_);
+                owned_.push_back(d_g1_);
+            }
+        }
         prog_wpw_ = wpw;
         prog_nwg_ = nwg;
         d_dep_ = dev_upload(dep.data(), dep.size());
         d_flags_ = dev_alloc<unsigned>(prog_flag_words(nwg));
-        d_err_ = dev_alloc<unsigned>(1);
-        HIPCHK(hipMemset(d_err_, 0, sizeof(unsigned)));
+        d_err_ = dev_alloc<unsigned>(64 + 16 * 1024);   // word 0: error bits; rest: debug stamps
+        HIPCHK(hipMemset(d_err_, 0, (64 + 16 * 1024) * sizeof(unsigned)));
         owned_.push_back(d_dep_);
         owned_.push_back(d_flags_);
         owned_.push_back(d_err_);
     }
+    // output pointer the next phase may gather from
+    auto gather_out = [](const RowOp &op) -> int64_t {
+        return (op.mode == EPI_LIN && op.y2.base >= 0) ? op.y2.off : op.y.off;
+    };
     std::vector<PcStep> out;
     size_t k = 0;
     while (k < steps_.size()) {
         size_t e = k;
-        while (e < steps_.size() && steps_[e].kind == PcStep::ROWS && steps_[e].rows.nops == 1) ++e;
+        while (e < steps_.size() && steps_[e].kind == PcStep::ROWS && steps_[e].rows.nops == 1) {
+            if (prog_granule_ && e > k) {
+                // data-flow form: phase ph >= 1 gathers exactly what phase ph-1 produced
+                const RowOp &op = steps_[e].rows.h_op, &prev = steps_[e - 1].rows.h_op;
+                bool chain = op.nterms > 0;
+                for (int t = 0; t < op.nterms; ++t)
+                    chain &= op.t[t].x.base == 0 && op.t[t].x.off == gather_out(prev);
+                if (!chain) break;
+            }
+            ++e;
+        }
         if (e - k >= 4) {
             std::vector<RowOp> ops;
             for (size_t q = k; q < e; ++q) {
@@ -156,14 +210,23 @@ void SchurPC::fuse_programs() {
             s.kind = PcStep::PROG;
             s.rows.d_ops = dev_upload(ops.data(), ops.size());
             s.nphases = (int)ops.size();
+            s.granule = prog_granule_;
             out.push_back(s);
             k = e;
         } else {
-            for (size_t q = k; q < std::max(e, k + 1); ++q) out.push_back(steps_[q]);
-            k = std::max(e, k + 1);
+            const size_t stop = std::max(e, k + 1);
+            for (size_t q = k; q < stop; ++q) out.push_back(steps_[q]);
+            k = stop;
         }
     }
     steps_.swap(out);
+}
+
+void SchurPC::debug_read(unsigned long long *out, int n) {
+    if (!d_err_) return;
+    HIPCHK(hipStreamSynchronize(S_.stream));
+    HIPCHK(hipMemcpy(out, d_err_ + 64, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(d_err_ + 64, 0, (size_t)n * 8));
 }
 
 void SchurPC::check() {
@@ -629,8 +692,12 @@ void SchurPC::replay(size_t first, size_t last) {
                 break;
             case PcStep::PROG: {
                 const Pattern &P = S_.patterns[m_pat_];
-                launch_row_program(st, s.rows.d_ops, s.nphases, prog_nwg_, prog_wpw_, P.R,
-                                   P.uniform_w, d_dep_, d_flags_, d_err_);
+                if (s.granule)
+                    launch_row_program_g(st, s.rows.d_ops, s.nphases, prog_nwg_, prog_wpw_,
+                                         P.uniform_w, d_g0_, d_g1_, granule_words_, d_err_);
+                else
+                    launch_row_program(st, s.rows.d_ops, s.nphases, prog_nwg_, prog_wpw_, P.R,
+                                       P.uniform_w, d_dep_, d_flags_, d_err_);
                 break;
             }
             case PcStep::COMM:

@@ -20,6 +20,7 @@ struct PcStep {
     const double *lo_halo = nullptr, *hi_halo = nullptr;   // TIME on a time shard
     int dst = -1, src = -1;         // COMM: send x to dst, receive y from src
     int nphases = 0;                // PROG: rows.d_ops holds nphases single-block RowOps
+    bool granule = false;           // PROG: data-flow form (tagged granules)
 };
 
 class SchurPC {
@@ -32,6 +33,7 @@ class SchurPC {
     double *out() { return out_; }
     void values_changed();
     void check();   // throws if a persistent row program reported a time-out
+    void debug_read(unsigned long long *out, int n);   // diagnostic builds (KKT_STAMPS)
     int bc_set() const { return bc_set_; }
     int64_t n_launches() const { return (int64_t)steps_.size(); }
 
@@ -73,6 +75,9 @@ class SchurPC {
     int prog_wpw_ = 0, prog_nwg_ = 0;
     int32_t *d_dep_ = nullptr;
     unsigned *d_flags_ = nullptr, *d_err_ = nullptr;
+    bool prog_granule_ = false;
+    unsigned long long *d_g0_ = nullptr, *d_g1_ = nullptr;
+    size_t granule_words_ = 0;
     void fuse_programs();
 
     struct Term {

@@ -66,13 +66,15 @@ def test_preconditioner_parity_many_workgroups(CN):
     ref = osys.pc_apply(common.oracle_pc(p, MASS, schur), x)
     got = common.gpu_system(p).pc_apply(x, common.gpu_pc(p, MASS, schur))
     assert common.rel_err(got, ref) < 1e-10
-    os.environ["KKT_PERSISTENT"] = "0"
-    try:
-        got2 = common.gpu_system(p).pc_apply(x, common.gpu_pc(p, MASS, schur))
-    finally:
-        del os.environ["KKT_PERSISTENT"]
-    # same arithmetic in the same order: launches and the persistent program agree exactly
-    assert np.array_equal(got, got2)
+    # same arithmetic in the same order: plain launches, the counter form and the data-flow
+    # form of the persistent program agree exactly
+    for var, val in (("KKT_PERSISTENT", "0"), ("KKT_PROG_MODE", "flags")):
+        os.environ[var] = val
+        try:
+            other = common.gpu_system(p).pc_apply(x, common.gpu_pc(p, MASS, schur))
+        finally:
+            del os.environ[var]
+        assert np.array_equal(got, other), var
 
 
 KRYLOV_SCHUR = (12, 0.08, 2.1)   # beta = 1e-2 on the 10x10 mesh: kappa(D^-1 S) ~ 25
