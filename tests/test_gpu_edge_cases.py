@@ -1,0 +1,226 @@
+"""Edge cases of the block system on the GPU against the oracle: ragged / empty rows
+(generic-width kernels), rectangular blocks, ConstantNullspace and FullNullspace, mixed
+boundary sets (automatic un-sharing of value arrays), the CN sub-block split, value
+updates, argument errors."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import common
+from control_amd.multiblock import (ConstantNullspace, DirichletBCNullspace, FullNullspace,
+                                    MultiBlockSystem, NoneNullspace)
+from oracle import kkt_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+
+def ragged(n_rows, n_cols, seed, density=0.02, empty_every=7, heavy_every=50):
+    """Random CSR with empty rows and a few very long rows (slice widths far from uniform)."""
+    rng = np.random.default_rng(seed)
+    A = sp.random(n_rows, n_cols, density=density, random_state=rng, format="lil")
+    for r in range(0, n_rows, empty_every):
+        A.rows[r], A.data[r] = [], []
+    for r in range(3, n_rows, heavy_every):
+        cols = np.sort(rng.choice(n_cols, size=min(n_cols, 40), replace=False))
+        A.rows[r], A.data[r] = list(cols), list(rng.standard_normal(len(cols)))
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    return A
+
+
+def pair(nx0, nx1, blocks, n0, n1, ns0, ns1, ons0, ons1, **kw):
+    g = MultiBlockSystem(nx0, nx1, *blocks, n_blocks_00=n0, n_blocks_11=n1, nullspace_0=ns0,
+                         nullspace_1=ns1, **kw)
+    okw = {k: v for k, v in kw.items() if k != "device"}
+    o = ko.OracleSystem(nx0, nx1, *blocks, n_blocks_00=n0, n_blocks_11=n1, nullspace_0=ons0,
+                        nullspace_1=ons1, **okw)
+    return g, o
+
+
+@pytest.mark.parametrize("sell_r", ["2", "1"])
+def test_ragged_rectangular_blocks_with_mixed_nullspaces(sell_r):
+    """2 + 3 blocks of different sizes, rectangular couplings, every nullspace kind, empty
+    rows, rows of 40 entries among rows of 3 (no uniform width -> generic kernels)."""
+    os.environ["KKT_SELL_R"] = sell_r
+    try:
+        nx0, nx1, n0, n1 = 301, 157, 2, 3
+        b00 = {(i, j): None for i in range(n0) for j in range(n0)}
+        b01 = {(i, j): None for i in range(n0) for j in range(n1)}
+        b10 = {(i, j): None for i in range(n1) for j in range(n0)}
+        b11 = {(i, j): None for i in range(n1) for j in range(n1)}
+        b00[(0, 0)] = ragged(nx0, nx0, 1)
+        b00[(1, 0)] = ragged(nx0, nx0, 2)
+        b00[(1, 1)] = b00[(0, 0)]                      # shared object
+        b01[(0, 1)] = ragged(nx0, nx1, 3)
+        b01[(1, 2)] = ragged(nx0, nx1, 4)
+        b10[(0, 0)] = ragged(nx1, nx0, 5)
+        b10[(2, 1)] = ragged(nx1, nx0, 6)
+        b11[(1, 1)] = ragged(nx1, nx1, 7)
+        b11[(2, 0)] = ragged(nx1, nx1, 8)               # block row 0 of variable 1 has no 11 term
+        bc0 = np.array([0, 5, 17, 300])
+        bc1 = np.array([1, 2, 156])
+        g, o = pair(nx0, nx1, (b00, b01, b10, b11), n0, n1,
+                    (DirichletBCNullspace(bc0, alpha=2.5), NoneNullspace()),
+                    (ConstantNullspace(alpha=0.5), DirichletBCNullspace(bc1), FullNullspace()),
+                    (ko.DirichletBCNullspace(bc0, alpha=2.5), ko.NoneNullspace()),
+                    (ko.ConstantNullspace(alpha=0.5), ko.DirichletBCNullspace(bc1),
+                     ko.FullNullspace()))
+        for seed in range(3):
+            x = common.rng_vector(o.N, 100 + seed)
+            assert common.rel_err(g.mult(x), o.mult(x)) < 1e-13
+
+        def pc(u_0, u_1, b_0, b_1):
+            u_0[:] = 3.0 * b_0
+            u_1[:] = b_1[::-1]
+        x = common.rng_vector(o.N, 7)
+        assert common.rel_err(g.pc_apply(x, pc), o.pc_apply(pc, x)) < 1e-14
+        assert common.rel_err(g.pc_apply(x, None),
+                              o.pc_apply(lambda a, b, c, d: (a.__setitem__(slice(None), c),
+                                                             b.__setitem__(slice(None), d)),
+                                         x)) < 1e-14
+    finally:
+        del os.environ["KKT_SELL_R"]
+
+
+def test_shared_values_with_different_boundary_sets_are_unshared():
+    """One matrix object used in two block columns whose Dirichlet sets differ: the column
+    masks differ, so the library must give the blocks separate value arrays."""
+    nx = 200
+    A = ragged(nx, nx, 11, density=0.05, empty_every=1000)
+    b00 = {(0, 0): A, (0, 1): A, (1, 0): None, (1, 1): A}
+    z = {(i, j): None for i in range(2) for j in range(1)}
+    zz = {(0, 0): None}
+    bca, bcb = np.arange(0, 20), np.arange(100, 140)
+    g = MultiBlockSystem(nx, 3, b00, z, {(0, 0): None, (0, 1): None}, zz, n_blocks_00=2,
+                         n_blocks_11=1, nullspace_0=(DirichletBCNullspace(bca),
+                                                     DirichletBCNullspace(bcb)))
+    o = ko.OracleSystem(nx, 3, b00, z, {(0, 0): None, (0, 1): None}, zz, n_blocks_00=2,
+                        n_blocks_11=1, nullspace_0=(ko.DirichletBCNullspace(bca),
+                                                    ko.DirichletBCNullspace(bcb)))
+    x = common.rng_vector(o.N, 3)
+    assert common.rel_err(g.mult(x), o.mult(x)) < 1e-13
+    assert g.info()["n_value_arrays"] == 1          # as added ...
+    assert g.info()["bytes_device_values"] > g.info()["nnz_blocks"] // 3 * 8   # ... then cloned
+
+
+def test_cn_sub_block_split():
+    """CN with sub_n_blocks (the incompressible layout, preconditioner.py:471-525): T_1 on the
+    first part of variable 0 and the second part of variable 1, T_2 on the others."""
+    nx0, nx1, n0, n1 = 90, 40, 6, 4
+    rngA = [ragged(nx0, nx0, 20 + k, density=0.06, empty_every=1000) for k in range(n0)]
+    rngB = [ragged(nx1, nx1, 40 + k, density=0.08, empty_every=1000) for k in range(n1)]
+    b00 = {(i, j): (rngA[i] if i == j else None) for i in range(n0) for j in range(n0)}
+    b11 = {(i, j): (rngB[i] if i == j else None) for i in range(n1) for j in range(n1)}
+    b01 = {(i, j): None for i in range(n0) for j in range(n1)}
+    b10 = {(i, j): None for i in range(n1) for j in range(n0)}
+    b01[(2, 1)] = ragged(nx0, nx1, 60)
+    b10[(3, 5)] = ragged(nx1, nx0, 61)
+    bc = np.array([0, 1, 2])
+    g, o = pair(nx0, nx1, (b00, b01, b10, b11), n0, n1,
+                tuple(DirichletBCNullspace(bc) for _ in range(n0)),
+                tuple(ConstantNullspace() for _ in range(n1)),
+                tuple(ko.DirichletBCNullspace(bc) for _ in range(n0)),
+                tuple(ko.ConstantNullspace() for _ in range(n1)),
+                CN=True, sub_n_blocks_00_0=3, sub_n_blocks_11_0=2)
+    x = common.rng_vector(o.N, 5)
+    assert common.rel_err(g.mult(x), o.mult(x)) < 1e-13
+
+
+def test_update_block_values_and_rebuilt_preconditioner():
+    """Picard-style re-linearisation: new values on the stored structure, operator and
+    built-in preconditioner follow (kkt_update_block_values)."""
+    p = common.heat_problem(n=10, n_t=6, share=False, time_dependent=True)
+    q = common.heat_problem(n=10, n_t=6, share=False, time_dependent=False)
+    gsys = common.gpu_system(p)
+    mass, schur = (20, 0.5, 2.0), (10, 0.2, 2.1)
+    gpc = common.gpu_pc(p, mass, schur)
+    x = common.rng_vector(2 * p["m"] * p["sd"].n_dofs)
+    gsys.pc_apply(x, gpc)                                  # builds the Schur matrices
+    for quad in range(4):
+        for (i, j), A in q["blocks"][quad].items():
+            if A is not None:
+                gsys.update_block_values(quad, i, j, A)
+    osys = common.oracle_system(q)
+    assert common.rel_err(gsys.mult(x), osys.mult(x)) < 1e-13
+    assert common.rel_err(gsys.pc_apply(x, gpc),
+                          osys.pc_apply(common.oracle_pc(q, mass, schur), x)) < 1e-10
+
+
+def test_argument_errors():
+    from control_amd import _lib
+    nx = 20
+    A = sp.identity(nx, format="csr")
+    with pytest.raises(ValueError, match="Unexpected dimension of blocks"):
+        MultiBlockSystem(nx, nx, {(0, 0): A}, {}, {(0, 0): A}, {(0, 0): A})
+    B = sp.identity(nx + 1, format="csr")
+    with pytest.raises(_lib.KktError, match="shape"):
+        MultiBlockSystem(nx, nx, {(0, 0): B}, {(0, 0): None}, {(0, 0): None}, {(0, 0): None})
+    with pytest.raises(_lib.KktError, match="out of range"):
+        MultiBlockSystem(nx, nx, {(0, 0): A}, {(0, 0): None}, {(0, 0): None}, {(0, 0): None},
+                         nullspace_0=(DirichletBCNullspace([nx + 3]),))
+    g = MultiBlockSystem(nx, nx, {(0, 0): A}, {(0, 0): None}, {(0, 0): None}, {(0, 0): A})
+    with pytest.raises(ValueError, match="linear_solver"):
+        g.solve(np.zeros((1, nx)), np.zeros((1, nx)), np.ones((1, nx)), np.ones((1, nx)),
+                solver_parameters={"linear_solver": "minres", "relative_tolerance": 1e-8,
+                                   "absolute_tolerance": 0.0})
+    with pytest.raises(KeyError):      # relative_tolerance is required (preconditioner.py:739)
+        g.solve(np.zeros((1, nx)), np.zeros((1, nx)), np.ones((1, nx)), np.ones((1, nx)),
+                solver_parameters={})
+    # identity system: one iteration, exact
+    u0, u1 = np.zeros((1, nx)), np.zeros((1, nx))
+    r = g.solve(u0, u1, np.ones((1, nx)), 2 * np.ones((1, nx)),
+                solver_parameters={"relative_tolerance": 1e-12, "absolute_tolerance": 0.0,
+                                   "monitor_convergence": False})
+    assert r.reason > 0 and np.allclose(u0, 1.0) and np.allclose(u1, 2.0)
+
+
+def test_full_size_operator_properties():
+    """BASELINE configs[1] at full size (8.45 M unknowns, mode S to keep host assembly short):
+    size-independent properties instead of an oracle run -- linearity, symmetry of the BE
+    KKT operator (block_01 = block_10^T), boundary rows, and bitwise repeatability."""
+    p = common.heat_problem(n=256, n_t=64)
+    g = common.gpu_system(p)
+    N = 2 * p["m"] * p["sd"].n_dofs
+    x, y = common.rng_vector(N, 1), common.rng_vector(N, 2)
+    Ax, Ay = g.mult(x), g.mult(y)
+    assert np.array_equal(Ax, g.mult(x))
+    a, b = 0.37, -1.9
+    assert common.rel_err(g.mult(a * x + b * y), a * Ax + b * Ay) < 1e-13
+    X = x.reshape(2 * p["m"], -1).copy()
+    Y = y.reshape(2 * p["m"], -1).copy()
+    X[:, p["nodes"]] = 0.0
+    Y[:, p["nodes"]] = 0.0
+    AX, AY = g.mult(X.ravel()), g.mult(Y.ravel())
+    assert abs(X.ravel() @ AY - Y.ravel() @ AX) < 1e-10 * abs(X.ravel() @ AY)
+    assert np.array_equal(Ax.reshape(2 * p["m"], -1)[:, p["nodes"]],
+                          x.reshape(2 * p["m"], -1)[:, p["nodes"]])
+
+
+def test_full_size_solve_reduces_true_residual_and_is_reproducible():
+    p = common.heat_problem(n=256, n_t=64, beta=1e-2)
+    g = common.gpu_system(p)
+    m, nx = p["m"], p["sd"].n_dofs
+    pc = common.gpu_pc(p, (20, 0.5, 2.0), (8, 0.07, 2.1))
+    X = p["sd"].coords
+    xs = np.stack([np.sin(np.pi * X[:, 0]) * np.sin(np.pi * X[:, 1]) * (1 + 0.01 * k)
+                   for k in range(2 * m)])
+    b = g.mult(xs.ravel()).reshape(2 * m, nx)
+    sp_ = {"linear_solver": "fgmres", "gmres_restart": 10, "maximum_iterations": 20,
+           "relative_tolerance": 1e-6, "absolute_tolerance": 0.0,
+           "monitor_convergence": False, "preconditioner": True}
+    runs = []
+    for _ in range(2):
+        u0, u1 = np.zeros((m, nx)), np.zeros((m, nx))
+        r = g.solve(u0, u1, b[:m].copy(), b[m:].copy(), solver_parameters=sp_, pc_fn=pc)
+        runs.append((np.vstack([u0, u1]), r.history))
+    assert np.array_equal(runs[0][0], runs[1][0])              # deterministic reductions
+    assert np.array_equal(runs[0][1], runs[1][1])
+    u = runs[0][0]
+    bc = b.copy()
+    bc[:, p["nodes"]] = 0.0
+    res = np.linalg.norm(bc.ravel() - g.mult(u.ravel()))
+    assert res < 0.9 * np.linalg.norm(bc)                      # true residual really went down
+    h = runs[0][1]
+    assert abs(h[-1] - res) < 1e-6 * h[0]                      # monitored norm is the true one
