@@ -746,6 +746,124 @@ void launch_row_program(hipStream_t s, const RowOp *d_ops, int nphases, int nwg,
                        reinterpret_cast<const int2 *>(d_dep), d_flags, d_err);
 }
 
+// Batched steps whose RowOps all apply the SAME matrix (the mass-Chebyshev steps and the
+// mass products of the preconditioner: one M for every time level): a thread loads its two
+// rows' indices and values once and serves NB time levels with them, so the per-non-zero
+// load issue -- the actual limiter of these launches, not HBM -- drops from (index, value,
+// 2 gathers) to (2 gathers + 1/NB of the rest).
+template <int W, int NB>
+__global__ __launch_bounds__(256) void pc_rows_shared(const RowOp *__restrict__ ops, int nops) {
+    constexpr int R = 2, C = 128;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + wave;
+    const int g0 = blockIdx.y * NB;
+    const RowOp &op0 = ops[g0];
+    if (s >= op0.nslices) return;
+    const size_t base = (size_t)s * W * C + (size_t)lane * R;
+    const int r0 = s * C + lane;
+    const int nrows = op0.nrows;
+    const Bases bases{{nullptr, nullptr, nullptr, nullptr}};
+    int c[W][R];
+    double v[W][R];
+    {
+        const gci_p colp = (gci_p)op0.col + base;
+        const gcd_p vp = (gcd_p)op0.t[0].vals + base;
+#pragma unroll
+        for (int k = 0; k < W; ++k) load_cols<R>(colp + (size_t)k * C, c[k]);
+#pragma unroll
+        for (int k = 0; k < W; ++k) load_vals<R, false>(vp + (size_t)k * C, v[k]);
+    }
+    const gcb_p rowmask = (gcb_p)op0.rowmask;
+    bool masked[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int r = r0 + 64 * q;
+        masked[q] = r < nrows && rowmask != nullptr && rowmask[r] != 0;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (g0 + b >= nops) break;
+        const RowOp &op = ops[g0 + b];
+        const bool lin = op.mode == EPI_LIN;
+        gcd_p pa, pb, pc, pd;
+        if (lin) {
+            pa = resolve(op.yin, bases);
+            pb = resolve(op.z, bases);
+            pc = resolve(op.mx, bases);
+            pd = op.y2.base >= 0 ? (gcd_p)op.dinv : nullptr;
+        } else {
+            pa = resolve(op.pkm1, bases);
+            pb = resolve(op.pk, bases);
+            pc = resolve(op.b, bases);
+            pd = (gcd_p)op.dinv;
+        }
+        double e0[R], e1[R], e2[R], e3[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int r = r0 + 64 * q;
+            const bool in = r < nrows;
+            e0[q] = (in && pa) ? pa[r] : 0.0;
+            e1[q] = (in && pb) ? pb[r] : 0.0;
+            e2[q] = (in && pc) ? pc[r] : 0.0;
+            e3[q] = (in && pd) ? pd[r] : 0.0;
+        }
+        const gcd_p x = resolve(op.t[0].x, bases);
+        double xv[W][R];
+#pragma unroll
+        for (int k = 0; k < W; ++k)
+#pragma unroll
+            for (int q = 0; q < R; ++q) xv[k][q] = x[c[k][q]];
+        double acc[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[q] = 0.0;
+#pragma unroll
+        for (int k = 0; k < W; ++k)
+#pragma unroll
+            for (int q = 0; q < R; ++q) acc[q] = __builtin_fma(v[k][q], xv[k][q], acc[q]);
+        const gd_p y = (gd_p)resolve(op.y, bases);
+        const gd_p y2 = lin && op.y2.base >= 0 ? (gd_p)resolve(op.y2, bases) : nullptr;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int r = r0 + 64 * q;
+            if (r >= nrows) continue;
+            double out, out2 = 0.0;
+            if (lin) {
+                if (masked[q]) {
+                    out = pc ? op.malpha * e2[q] : 0.0;
+                } else {
+                    out = op.ca * acc[q];
+                    if (pa) out += op.cy * e0[q];
+                    if (pb) out += op.cz * e1[q];
+                }
+                out2 = op.c3 * (e3[q] * out);
+            } else if (masked[q]) {
+                out = 0.0;
+            } else {
+                double t = pa ? op.c1 * e0[q] : 0.0;
+                if (pb) t += op.c2 * e1[q];
+                t += op.c3 * (e3[q] * (e2[q] - acc[q]));
+                out = op.post2 * (op.post1 * t);
+            }
+            y[r] = out;
+            if (y2) y2[r] = out2;
+        }
+    }
+}
+
+bool launch_rowops_shared(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, int R,
+                          int uniform_w) {
+    constexpr int NB = 4;
+    if (R != 2 || nops < NB) return false;
+    const dim3 grid((max_slices + 3) / 4, (nops + NB - 1) / NB), block(256);
+    switch (uniform_w) {
+#define KKT_W(n) case n: hipLaunchKernelGGL((pc_rows_shared<n, NB>), grid, block, 0, s, d_ops, nops); return true;
+        KKT_W(1) KKT_W(2) KKT_W(3) KKT_W(4) KKT_W(5) KKT_W(6) KKT_W(7) KKT_W(8)
+#undef KKT_W
+        default: return false;
+    }
+}
+
 template <int R, int WFIX>
 static void launch_one(hipStream_t s, dim3 grid, const RowOp *d_ops, const Bases &bases, int tag,
                        const RowOp *h_single) {

@@ -56,6 +56,11 @@ void launch_rowops(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, 
                    const Bases &bases, int tag, int uniform_w,
                    const RowOp *h_single = nullptr);
 
+// Batched launch for RowOps that all have ONE term with the same matrix and pattern
+// (uniform width 1..8, R = 2): four time levels per thread.  Returns false if not applicable.
+bool launch_rowops_shared(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, int R,
+                          int uniform_w);
+
 // One persistent launch that runs `nphases` single-block RowOps in order, workgroup j
 // waiting before each phase for the workgroups d_dep[2j] .. d_dep[2j+1] (kernels.hip).
 int prog_flag_words(int nwg);

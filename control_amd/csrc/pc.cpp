@@ -330,6 +330,15 @@ void SchurPC::push_rows(std::vector<RowOp> &r) {
         s.rows.single = kernarg_ops;
         s.rows.h_op = r[0];
     }
+    static const bool use_shared = [] {
+        const char *e = std::getenv("KKT_SHARED_ROWS");
+        return !(e && e[0] == '0');
+    }();
+    s.rows.shared_matrix = use_shared && r.size() >= 4;
+    for (const RowOp &op : r)
+        s.rows.shared_matrix = s.rows.shared_matrix && op.nterms == 1 &&
+                               op.t[0].vals == r[0].t[0].vals && op.col == r[0].col &&
+                               op.rowmask == r[0].rowmask && op.t[0].x.base == 0;
     steps_.push_back(s);
 }
 
@@ -681,6 +690,10 @@ void SchurPC::replay(size_t first, size_t last) {
         const PcStep &s = steps_[k];
         switch (s.kind) {
             case PcStep::ROWS:
+                if (s.rows.shared_matrix &&
+                    launch_rowops_shared(st, s.rows.d_ops, s.rows.nops, s.rows.max_slices,
+                                         s.rows.R, s.rows.uniform_w))
+                    break;
                 launch_rowops(st, s.rows.d_ops, s.rows.nops, s.rows.max_slices, s.rows.R, B, 1,
                               s.rows.uniform_w, s.rows.single ? &s.rows.h_op : nullptr);
                 break;

@@ -86,6 +86,7 @@ struct RowLaunch {
     int R = 2;
     int uniform_w = -1;   // > 0: every op with terms in this launch has this slice width
     bool single = false;  // nops == 1: h_op rides in the kernel arguments
+    bool shared_matrix = false;   // every op has one term with the same matrix
     RowOp h_op;
 };
 
