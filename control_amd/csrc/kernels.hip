@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void pc_row_step(const RowOp op, const Bases b
 // workgroup per CU.  Every spin is bounded: on a time-out the error word is set and the
 // kernel runs to its end (results invalid, reported by the host) instead of hanging.
 constexpr int FLAG_STRIDE = 32;                 // one 128-byte line per workgroup counter
-constexpr unsigned PROG_SPIN_LIMIT = 1u << 22;
+constexpr unsigned PROG_SPIN_LIMIT = 1u << 20;
 
 template <int R, int WFIX>
 __global__ __launch_bounds__(512) void pc_row_program(const RowOp *__restrict__ ops, int nphases,
@@ -341,6 +341,7 @@ __global__ __launch_bounds__(512) void pc_row_program(const RowOp *__restrict__ 
     const int s = j * wpw + wave;
     const int2 d = dep[j];
     const Bases B{{nullptr, nullptr, nullptr, nullptr}};
+    bool dead = false;   // a spin timed out: stop waiting, run to the end, results invalid
     for (int ph = 0; ph < nphases; ++ph) {
         if (ph > 0) {
             if (wave == 0) {
@@ -351,10 +352,13 @@ __global__ __launch_bounds__(512) void pc_row_program(const RowOp *__restrict__ 
                     ok = jj > d.y || __hip_atomic_load(flags + (size_t)jj * FLAG_STRIDE,
                                                        __ATOMIC_RELAXED,
                                                        __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)ph;
-                    if (__all(ok)) break;
+                    if (__all(ok) || dead) break;
                     __builtin_amdgcn_s_sleep(1);
                 } while (++spins < PROG_SPIN_LIMIT);
-                if (!__all(ok) && lane == 0) atomicOr(err, 1u);
+                if (!__all(ok)) {
+                    dead = true;
+                    if (lane == 0) atomicOr(err, 1u);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __syncthreads();
@@ -472,6 +476,7 @@ __global__ __launch_bounds__(512) void pc_row_program_g(const RowOp *__restrict_
         return (size_t)lane * 8 < sizeof(RowOp) ? p[lane] : 0ull;
     };
     unsigned long long dnext = load_desc(0);
+    bool dead = false;   // a spin timed out: stop waiting, run to the end, results invalid
     for (int ph = 0; ph < nphases; ++ph) {
         const unsigned long long desc = dnext;
         if (ph + 1 < nphases) dnext = load_desc(ph + 1);   // in flight during this phase
@@ -574,9 +579,12 @@ __global__ __launch_bounds__(512) void pc_row_program_g(const RowOp *__restrict_
                             xv[k][q] = __longlong_as_double(
                                 (long long)((a & 0xffffffffull) | (b << 32)));
                         }
-                    if (__all(ok)) break;
+                    if (__all(ok) || dead) break;
                 } while (++spins < PROG_SPIN_LIMIT);
-                if (!__all(ok) && lane == 0) atomicOr(err, 2u);
+                if (!__all(ok)) {
+                    dead = true;
+                    if (lane == 0) atomicOr(err, 2u);
+                }
             }
         }
         KKT_STAGE(3);   // gather
