@@ -178,3 +178,80 @@ def unit_square_q2(n: int) -> SpatialDiscretisation:
     return SpatialDiscretisation(_canonical_csr(M), _canonical_csr(K), coords,
                                  np.flatnonzero(onb).astype(np.int32),
                                  f"Q2 {n}x{n}")
+
+
+# --------------------------------------------------------------- Taylor-Hood (Q2-Q1)
+
+def _gauss(npts=4):
+    x, w = np.polynomial.legendre.leggauss(npts)
+    return 0.5 * (x + 1.0), 0.5 * w          # on [0, 1]
+
+
+def _p1p2_1d(n: int, length: float):
+    """1-D mixed matrices between P1 (n+1 nodes) test and P2 (2n+1 nodes) trial functions:
+    ``MX[i, j] = int psi_i phi_j`` and ``DX[i, j] = int psi_i phi_j'``; plus P1 mass/stiffness."""
+    h = length / n
+    xq, wq = _gauss(4)
+    psi = np.stack([1.0 - xq, xq])                                    # P1 on [0,1]
+    phi = np.stack([2 * (xq - 0.5) * (xq - 1.0), 4 * xq * (1.0 - xq), 2 * xq * (xq - 0.5)])
+    dphi = np.stack([4 * xq - 3.0, 4.0 - 8 * xq, 4 * xq - 1.0])       # d/d(xi)
+    MXe = h * np.einsum("iq,jq,q->ij", psi, phi, wq)
+    DXe = np.einsum("iq,jq,q->ij", psi, dphi, wq)                     # h * (1/h)
+    M1e = h * np.einsum("iq,jq,q->ij", psi, psi, wq)
+    K1e = (1.0 / h) * np.array([[1.0, -1.0], [-1.0, 1.0]])
+    MX = sp.lil_matrix((n + 1, 2 * n + 1))
+    DX = sp.lil_matrix((n + 1, 2 * n + 1))
+    M1 = sp.lil_matrix((n + 1, n + 1))
+    K1 = sp.lil_matrix((n + 1, n + 1))
+    for e in range(n):
+        ip = np.array([e, e + 1])
+        iv = np.array([2 * e, 2 * e + 1, 2 * e + 2])
+        MX[np.ix_(ip, iv)] += MXe
+        DX[np.ix_(ip, iv)] += DXe
+        M1[np.ix_(ip, ip)] += M1e
+        K1[np.ix_(ip, ip)] += K1e
+    return sp.csr_matrix(MX), sp.csr_matrix(DX), sp.csr_matrix(M1), sp.csr_matrix(K1)
+
+
+@dataclass
+class TaylorHoodDiscretisation:
+    """Q2 velocity (two components, component-major dof order) and Q1 pressure on
+    ``UnitSquareMesh(n, n, quadrilateral=True)`` -- the spaces of the reference's
+    incompressible known-answer test (``test/test_control.py:232-237``)."""
+    M_v: sp.csr_matrix        # vector mass
+    K_v: sp.csr_matrix        # vector grad-grad
+    B: sp.csr_matrix          # -(div v, q): shape (n_p, n_v)
+    M_p: sp.csr_matrix
+    K_p: sp.csr_matrix
+    coords_v: np.ndarray      # (n_v / 2, 2) node coordinates of one component
+    coords_p: np.ndarray
+    boundary_v: np.ndarray    # Dirichlet dofs of the vector space (both components)
+
+    @property
+    def n_v(self):
+        return self.M_v.shape[0]
+
+    @property
+    def n_p(self):
+        return self.M_p.shape[0]
+
+
+def unit_square_q2q1(n: int) -> TaylorHoodDiscretisation:
+    sd = unit_square_q2(n)
+    M2, K2 = sd.M, sd.K
+    I2 = sp.identity(2, format="csr")
+    M_v = _canonical_csr(sp.kron(I2, M2))
+    K_v = _canonical_csr(sp.kron(I2, K2))
+    MX, DX, M1, K1 = _p1p2_1d(n, 1.0)
+    # dof (i, j) -> j * n_nodes_x + i  (y index major), as in unit_square_q2
+    Bx = sp.kron(MX, DX)          # int q  d(v_x)/dx : (y: psi*phi) x (x: psi*phi')
+    By = sp.kron(DX, MX)          # int q  d(v_y)/dy
+    B = _canonical_csr(-sp.hstack([Bx, By]))
+    M_p = _canonical_csr(sp.kron(M1, M1))
+    K_p = _canonical_csr(sp.kron(M1, K1) + sp.kron(K1, M1))
+    xs = np.linspace(0.0, 1.0, n + 1)
+    XX, YY = np.meshgrid(xs, xs, indexing="xy")
+    coords_p = np.stack([XX.ravel(), YY.ravel()], axis=1)
+    nb = sd.boundary
+    boundary_v = np.concatenate([nb, nb + sd.n_dofs]).astype(np.int32)
+    return TaylorHoodDiscretisation(M_v, K_v, B, M_p, K_p, sd.coords, coords_p, boundary_v)

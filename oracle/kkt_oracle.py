@@ -722,3 +722,63 @@ def pc_instationary_CN(M, block_01, block_10, n_t, tau, beta, nodes, mass_spec,
             _bc(b[i], nodes)
             u_1[i] = solve(block_01[(i, i)], my_const, b[i])
     return pc_linear
+
+
+# ------------------------------------------------ incompressible (Stokes) control, stationary
+
+
+def stationary_incompressible_blocks(M_v, D_v, B, beta):
+    """Outer block system of ``Stationary.incompressible_linear_solve``
+    (``control/control.py:896-919``): ``space_0`` blocks (v, zeta), ``space_1`` blocks (mu, p)."""
+    D_zeta = sp.csr_matrix(D_v.T)
+    B = sp.csr_matrix(B)
+    B_T = sp.csr_matrix(B.T)
+    b00 = {(0, 0): M_v, (0, 1): D_zeta, (1, 0): D_v, (1, 1): sp.csr_matrix((-1.0 / beta) * M_v)}
+    b01 = {(0, 0): B_T, (0, 1): None, (1, 0): None, (1, 1): B_T}
+    b10 = {(0, 0): B, (0, 1): None, (1, 0): None, (1, 1): B}
+    b11 = {(0, 0): None, (0, 1): None, (1, 0): None, (1, 1): None}
+    return b00, b01, b10, b11
+
+
+def pc_stationary_incompressible(M_v, D_v, B, M_p, K_p, D_p, beta, nodes_v, mass_spec,
+                                 schur_spec, kp_spec, mp_spec, inner_its=5):
+    """``pc_fn`` of ``Stationary.incompressible_linear_solve`` (``control/control.py:986-1085``):
+    ``inner_its`` GMRES iterations on the velocity KKT block with the stationary block-Schur
+    preconditioner (``:993-1024``), then the pressure Schur complement
+    ``M_p^-1 [[M_p, D_p^T], [D_p, -M_p/beta]] K_p^-1`` (``:1030-1082``).  ``kp_spec`` replaces the
+    single BoomerAMG cycle on ``K_p`` (north_star), ``mp_spec`` is the reference's own
+    20-step Jacobi-Chebyshev on ``M_p`` (``:957-971``).  ``D_p`` is the forward operator
+    assembled on the pressure space (``:981``)."""
+    D_zeta = sp.csr_matrix(D_v.T)
+    nv = M_v.shape[0]
+    ib00 = {(0, 0): M_v}
+    ib01 = {(0, 0): D_zeta}
+    ib10 = {(0, 0): D_v}
+    ib11 = {(0, 0): sp.csr_matrix((-1.0 / beta) * M_v)}
+    inner = OracleSystem(nv, nv, ib00, ib01, ib10, ib11,
+                         nullspace_0=(DirichletBCNullspace(nodes_v),),
+                         nullspace_1=(DirichletBCNullspace(nodes_v),))
+    inner_pc = pc_stationary(M_v, D_v, D_zeta, beta, nodes_v, mass_spec, schur_spec)
+    inner_sp = {"preconditioner": True, "linear_solver": "gmres",
+                "maximum_iterations": inner_its, "relative_tolerance": 0.0,
+                "absolute_tolerance": 0.0, "monitor_convergence": False}
+    K_p = sp.csr_matrix(K_p)
+    M_p = sp.csr_matrix(M_p)
+    D_p = sp.csr_matrix(D_p)
+    D_pT = sp.csr_matrix(D_p.T)
+
+    def pc_fn(u_0, u_1, b_0, b_1):
+        v = np.zeros(nv)
+        z = np.zeros(nv)
+        inner.solve(v[None, :], z[None, :], b_0[0:1], b_0[1:2], solver_parameters=inner_sp,
+                    pc_fn=inner_pc)
+        u_0[0], u_0[1] = v, z
+        h0 = B @ v - b_1[0]
+        h1 = B @ z - b_1[1]
+        m0 = _inner_solve(K_p, kp_spec, h0)
+        m1 = _inner_solve(K_p, kp_spec, h1)
+        g0 = M_p @ m0 + D_pT @ m1
+        g1 = D_p @ m0 + (-1.0 / beta) * (M_p @ m1)
+        u_1[0] = _inner_solve(M_p, mp_spec, g0)
+        u_1[1] = _inner_solve(M_p, mp_spec, g1)
+    return pc_fn

@@ -106,3 +106,34 @@ def kat_instationary_CN():
             b_1[i] -= (h / beta) * (M @ z[i + 1])
     return dict(sd=sd, beta=beta, tau=tau, n_t=n_t, v_ref=v, z_ref=z,
                 b_0=b_0, b_1=b_1, nodes=sd.boundary)
+
+
+def kat_stationary_incompressible():
+    """``test/test_control.py:232-358``: Q2-Q1 on a 4x4 quadrilateral mesh, forward operator
+    grad-grad + mass, beta = 1e-3, homogeneous Dirichlet velocity, ConstantNullspace on both
+    pressures, Chebyshev bounds (0.25, 1.5625) velocity mass and (0.25, 2.25) pressure mass,
+    FGMRES to 1e-15, all four fields within 1e-13 in L2 (pressures up to their means)."""
+    from control_amd.fem import unit_square_q2q1
+    th = unit_square_q2q1(4)
+    X, Y = th.coords_v[:, 0], th.coords_v[:, 1]
+    xp, yp = th.coords_p[:, 0], th.coords_p[:, 1]
+    s12 = np.sin(np.pi * X) * np.sin(2.0 * np.pi * Y)
+    s34 = np.sin(3.0 * np.pi * X) * np.sin(4.0 * np.pi * Y)
+    v_ref = np.concatenate([X * np.exp(Y) * s12, s34])            # :278-280
+    z_ref = np.concatenate([s12, s34])                            # :281-283
+    p_ref = np.sin(np.pi * xp) * np.sin(2.0 * np.pi * yp)         # :287
+    mu_ref = xp * np.exp(yp)                                      # :288
+    beta = BETA
+    D = th.K_v + th.M_v                                           # :243-245
+    BT = th.B.T
+    b_0 = th.M_v @ v_ref + D @ z_ref + BT @ mu_ref                # :295-298
+    b_1 = D @ v_ref - (1.0 / beta) * (th.M_v @ z_ref) + BT @ p_ref   # :299-302
+    b_2 = th.B @ v_ref                                            # :303
+    b_3 = th.B @ z_ref                                            # :304
+    return dict(th=th, D=D, D_p=th.K_p + th.M_p, beta=beta, v_ref=v_ref, z_ref=z_ref,
+                p_ref=p_ref, mu_ref=mu_ref, b_0=np.stack([b_0, b_1]), b_1=np.stack([b_2, b_3]),
+                lambda_p_bounds=(0.25, 2.25),
+                solver_parameters={"linear_solver": "fgmres", "fgmres_restart": 10,
+                                   "maximum_iterations": 500, "relative_tolerance": 1.0e-15,
+                                   "absolute_tolerance": 1.0e-15,
+                                   "monitor_convergence": False})
