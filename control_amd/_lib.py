@@ -34,6 +34,16 @@ class PcDesc(C.Structure):
                 ("schur_emax", C.c_double)]
 
 
+class PcStokesDesc(C.Structure):
+    _fields_ = [("n_p_blocks", C.c_int), ("nv", C.c_int64), ("np", C.c_int64),
+                ("b_scale", C.c_double), ("post_scale", C.c_double),
+                ("b_indptr", c_i32p), ("b_indices", c_i32p), ("b_values", c_f64p),
+                ("kp_indptr", c_i32p), ("kp_indices", c_i32p), ("kp_values", c_f64p),
+                ("mp_indptr", c_i32p), ("mp_indices", c_i32p), ("mp_values", c_f64p),
+                ("kp_its", C.c_int), ("kp_emin", C.c_double), ("kp_emax", C.c_double),
+                ("mp_its", C.c_int), ("mp_emin", C.c_double), ("mp_emax", C.c_double)]
+
+
 class Info(C.Structure):
     _fields_ = [(n, C.c_int64) for n in
                 ("n_local", "n_blocks_stored", "n_value_arrays", "n_patterns",
@@ -68,6 +78,8 @@ SIGNATURES = {
     "kkt_set_const_nullspace": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     "kkt_finalize": (C.c_int, [C.c_void_p]),
     "kkt_set_pc_schur": (C.c_int, [C.c_void_p, C.POINTER(PcDesc)]),
+    "kkt_set_pc_stokes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.POINTER(PcStokesDesc)]),
     "kkt_set_pc_callback": (C.c_int, [C.c_void_p, PC_CALLBACK, C.c_void_p]),
     "kkt_set_pc_identity": (C.c_int, [C.c_void_p]),
     "kkt_set_krylov": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double,

@@ -108,6 +108,16 @@ int kkt_set_pc_schur(kkt_handle h, const kkt_pc_desc *desc) {
     });
 }
 
+int kkt_set_pc_stokes(kkt_handle h, kkt_handle inner, kkt_handle commutator,
+                      const kkt_pc_stokes_desc *desc) {
+    KKT_TRY(h, {
+        if (!desc || !inner || !commutator) fail(KKT_ERR_ARG, "null argument");
+        S.pc.reset();
+        S.pc_cb = nullptr;
+        S.pc.reset(new StokesPC(S, inner->S, commutator->S, *desc));
+    });
+}
+
 int kkt_set_pc_callback(kkt_handle h, kkt_pc_callback fn, void *user) {
     KKT_TRY(h, {
         if (!fn) fail(KKT_ERR_ARG, "null callback");

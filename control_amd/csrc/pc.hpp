@@ -23,17 +23,30 @@ struct PcStep {
     bool granule = false;           // PROG: data-flow form (tagged granules)
 };
 
-class SchurPC {
+// A device-resident pc_fn: reads the nullspace-corrected right-hand side from in(), leaves
+// pc_fn(b) in out() (both n_local doubles, fixed buffers).
+class PcBase {
+   public:
+    virtual ~PcBase() {}
+    virtual void run() = 0;
+    virtual double *in() = 0;
+    virtual double *out() = 0;
+    virtual void values_changed() {}
+    virtual void check() {}
+    virtual void debug_read(unsigned long long *, int) {}
+};
+
+class SchurPC : public PcBase {
    public:
     SchurPC(System &S, const kkt_pc_desc &d);
-    ~SchurPC();
+    ~SchurPC() override;
     // u = pc_fn(b) on the fixed internal vectors in_ / out_ (bc-corrected by the caller)
-    void run();
-    double *in() { return in_; }
-    double *out() { return out_; }
-    void values_changed();
-    void check();   // throws if a persistent row program reported a time-out
-    void debug_read(unsigned long long *out, int n);   // diagnostic builds (KKT_STAMPS)
+    void run() override;
+    double *in() override { return in_; }
+    double *out() override { return out_; }
+    void values_changed() override;
+    void check() override;   // throws if a persistent row program reported a time-out
+    void debug_read(unsigned long long *out, int n) override;   // diagnostic builds (KKT_STAMPS)
     int bc_set() const { return bc_set_; }
     int64_t n_launches() const { return (int64_t)steps_.size(); }
 
@@ -125,6 +138,44 @@ class SchurPC {
     void build_BE();
     void build_CN();
     void replay(size_t first, size_t last);
+};
+
+// Preconditioner of the incompressible (Stokes / Navier-Stokes) control systems:
+// the pc_fn closures of Stationary.incompressible_linear_solve (reference
+// control/control.py:986-1085) and Instationary.incompressible_linear_solve, BE branch
+// (control.py:4515-4687).  u_0 = `inner_its` GMRES iterations on the velocity KKT system
+// (a second handle with its own block-Schur preconditioner); then per pressure block
+// h = s2 (sB B u_0 - b_1), m = K_p^-1 h (Jacobi-Chebyshev in place of one BoomerAMG cycle),
+// g = C m with C the pressure-space commutator block system (a third handle), and
+// u_1 = M_p^-1 g (20 Jacobi-Chebyshev steps, control.py:957-971).
+class StokesPC : public PcBase {
+   public:
+    StokesPC(System &outer, System &inner, System &commutator, const kkt_pc_stokes_desc &d);
+    ~StokesPC() override;
+    void run() override;
+    double *in() override { return in_; }
+    double *out() override { return out_; }
+    void check() override;
+
+   private:
+    System &S_, &inner_, &comm_;
+    int n_ = 1;   // pressure blocks per variable
+    int64_t nv_ = 0, np_ = 0;
+    double sB_ = 1.0, s2_ = 1.0;
+    int kp_its_ = 0, mp_its_ = 0;
+    double kp_emin_ = 0, kp_emax_ = 0, mp_emin_ = 0, mp_emax_ = 0;
+    struct DevMat {
+        int pat = -1;
+        double *vals = nullptr, *dinv = nullptr;
+    } B_, Kp_, Mp_;
+    double *in_ = nullptr, *out_ = nullptr, *h_ = nullptr, *m_ = nullptr, *g_ = nullptr;
+    double *P_[3] = {nullptr, nullptr, nullptr};
+    std::vector<void *> owned_;
+    std::vector<RowLaunch> lin_, kp_steps_, mp_steps_;
+    DevMat upload(int64_t nrows, int64_t ncols, const int32_t *ip, const int32_t *ix,
+                  const double *v, bool want_dinv);
+    void emit_cheb(std::vector<RowLaunch> &dst, const DevMat &A, int its, double emin, double emax,
+                   const double *b, double *out);
 };
 
 }  // namespace kkt

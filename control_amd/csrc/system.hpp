@@ -97,7 +97,7 @@ struct TimeGroup {   // CN transform applied to a contiguous range of local bloc
     int64_t nx;
 };
 
-class SchurPC;
+class PcBase;
 class Comm;
 
 struct KrylovCfg {
@@ -157,7 +157,7 @@ struct System {
     kkt_info info{};
 
     // preconditioner
-    std::unique_ptr<SchurPC> pc;
+    std::unique_ptr<PcBase> pc;
     kkt_pc_callback pc_cb = nullptr;
     void *pc_cb_user = nullptr;
     bool pc_cb_failed = false;

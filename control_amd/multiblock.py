@@ -18,7 +18,8 @@ import numpy as np
 from . import _lib
 
 __all__ = ["Nullspace", "NoneNullspace", "ConstantNullspace", "DirichletBCNullspace",
-           "FullNullspace", "MultiBlockSystem", "SchurPC", "KSPResult", "ChebSpec"]
+           "FullNullspace", "MultiBlockSystem", "SchurPC", "StokesPC", "KSPResult",
+           "ChebSpec"]
 
 Q00, Q01, Q10, Q11 = 0, 1, 2, 3
 _KSP_TYPES = {"gmres": 0, "fgmres": 1}
@@ -91,6 +92,31 @@ class SchurPC:
     n_t: int = 1
     tau: float = 1.0
     epsilon: float = 1.0e-3
+
+
+@dataclass
+class StokesPC:
+    """Built-in preconditioner of the incompressible control systems, run on the GPU
+    (``kkt_set_pc_stokes``): the ``pc_fn`` closures of
+    ``Stationary.incompressible_linear_solve`` (``control/control.py:986-1085``) and the BE
+    branch of ``Instationary.incompressible_linear_solve`` (``control.py:4515-4687``).
+
+    ``inner``: the velocity KKT ``MultiBlockSystem``; ``inner_pc``: its ``SchurPC``;
+    ``commutator``: the pressure-space block system ``block_**_int_p``; ``B, K_p, M_p``:
+    divergence, pressure stiffness and pressure mass matrices.
+    """
+    inner: object
+    inner_pc: object
+    commutator: object
+    B: object
+    K_p: object
+    M_p: object
+    kp: ChebSpec
+    mp: ChebSpec
+    n_p_blocks: int = 1
+    b_scale: float = 1.0
+    post_scale: float = 1.0
+    inner_its: int = 5            # control.py:1005-1010
 
 
 class KSPResult:
@@ -309,6 +335,27 @@ class MultiBlockSystem:
                 schur_emin=float(pc_fn.schur.emin), schur_emax=float(pc_fn.schur.emax))
             self._ck(self._lib.kkt_set_pc_schur(self._h, C.byref(d)))
             self._pc_state = pc_fn
+        elif isinstance(pc_fn, StokesPC):
+            if self._pc_state is pc_fn:
+                return
+            inner, comm = pc_fn.inner, pc_fn.commutator
+            inner._set_pc(pc_fn.inner_pc)
+            # inner_solver_parameters of control.py:1005-1010: gmres, 5 iterations, no test
+            self._ck(self._lib.kkt_set_krylov(inner._h, 0, -1, 30, 0.0, 0.0, -1.0,
+                                              int(pc_fn.inner_its)))
+            mats = [_as_csr(A) for A in (pc_fn.B, pc_fn.K_p, pc_fn.M_p)]
+            d = _lib.PcStokesDesc(
+                n_p_blocks=int(pc_fn.n_p_blocks), nv=self._nx0, np=self._nx1,
+                b_scale=float(pc_fn.b_scale), post_scale=float(pc_fn.post_scale),
+                kp_its=int(pc_fn.kp.its), kp_emin=float(pc_fn.kp.emin),
+                kp_emax=float(pc_fn.kp.emax), mp_its=int(pc_fn.mp.its),
+                mp_emin=float(pc_fn.mp.emin), mp_emax=float(pc_fn.mp.emax))
+            for name, (ip, ix, va) in zip(("b", "kp", "mp"), mats):
+                setattr(d, name + "_indptr", ip.ctypes.data_as(_lib.c_i32p))
+                setattr(d, name + "_indices", ix.ctypes.data_as(_lib.c_i32p))
+                setattr(d, name + "_values", va.ctypes.data_as(_lib.c_f64p))
+            self._ck(self._lib.kkt_set_pc_stokes(self._h, inner._h, comm._h, C.byref(d)))
+            self._pc_state = pc_fn          # keeps inner and commutator alive
         elif callable(pc_fn):
             n0, n1, nx0, nx1 = self._n0_loc, self._n1_loc, self._nx0, self._nx1
 
@@ -331,7 +378,7 @@ class MultiBlockSystem:
             self._ck(self._lib.kkt_set_pc_callback(self._h, cb, None))
             self._pc_state = pc_fn
         else:
-            raise TypeError("pc_fn must be None, a SchurPC descriptor or a callable")
+            raise TypeError("pc_fn must be None, a SchurPC / StokesPC descriptor or a callable")
 
     # -- preconditioner.py:337-786
     def solve(self, u_0, u_1, b_0, b_1, *, solver_parameters=None, pc_fn=None):

@@ -141,6 +141,33 @@ typedef struct kkt_pc_desc {
 
 int kkt_set_pc_schur(kkt_handle h, const kkt_pc_desc *desc);
 
+/* Preconditioner of the incompressible control systems: the pc_fn closures of
+ * Stationary.incompressible_linear_solve (control.py:986-1085) and the BE branch of
+ * Instationary.incompressible_linear_solve (control.py:4515-4687).  `h` is the outer system
+ * (variable 0 = velocity blocks v then zeta, variable 1 = pressure blocks mu then p); `inner`
+ * is the velocity KKT system with its own preconditioner and KSP options already set
+ * (the reference runs 5 GMRES iterations, control.py:1005-1010); `commutator` is the
+ * pressure-space block system block_**_int_p (control.py:976-984, 3818-3820).  Both handles
+ * must stay alive while `h` uses them.  B = -(div v, q) is the unscaled divergence block. */
+typedef struct kkt_pc_stokes_desc {
+    int n_p_blocks;          /* pressure blocks per variable (1 stationary, n_t BE) */
+    int64_t nv, np;          /* dofs of one velocity / pressure block */
+    double b_scale;          /* tau (instationary, control.py:4577) or 1 */
+    double post_scale;       /* 1 / tau^2 (control.py:4596-4601) or 1 */
+    const int32_t *b_indptr, *b_indices;      /* B: np x nv */
+    const double *b_values;
+    const int32_t *kp_indptr, *kp_indices;    /* K_p: np x np */
+    const double *kp_values;
+    const int32_t *mp_indptr, *mp_indices;    /* M_p: np x np */
+    const double *mp_values;
+    int kp_its;              /* Jacobi-Chebyshev steps replacing the BoomerAMG cycle on K_p */
+    double kp_emin, kp_emax;
+    int mp_its;              /* control.py:957-971: 20 (0: one Jacobi application, :973-979) */
+    double mp_emin, mp_emax;
+} kkt_pc_stokes_desc;
+int kkt_set_pc_stokes(kkt_handle h, kkt_handle inner, kkt_handle commutator,
+                      const kkt_pc_stokes_desc *desc);
+
 /* Arbitrary user `pc_fn(u_0, u_1, b_0, b_1)` (preconditioner.py:337-345, 623-627) on host
  * arrays: slow path kept for API parity (`P=` of every *_solve, control.py:3257-3258).
  * The library downloads b, calls `fn`, uploads u.  Non-zero return -> the solve fails

@@ -209,3 +209,68 @@ def test_kat_stationary():
     assert res.reason > 0
     assert kat.l2_norm(sd.M, v - p["v_ref"]) < 1.0e-13
     assert kat.l2_norm(sd.M, z - p["z_ref"]) < 1.0e-13
+
+
+def _stokes_systems(p):
+    """Outer Stokes-control system + velocity KKT + pressure commutator on the GPU."""
+    from control_amd.multiblock import (ChebSpec, ConstantNullspace, DirichletBCNullspace,
+                                        MultiBlockSystem, SchurPC, StokesPC)
+    from oracle import kkt_oracle as ko
+    import scipy.sparse as sp
+    th, beta = p["th"], p["beta"]
+    D, D_p = p["D"], p["D_p"]
+    blocks = ko.stationary_incompressible_blocks(th.M_v, D, th.B, beta)
+    nsv = DirichletBCNullspace(th.boundary_v)
+    outer = MultiBlockSystem(th.n_v, th.n_p, *blocks, n_blocks_00=2, n_blocks_11=2,
+                             nullspace_0=(nsv, nsv),
+                             nullspace_1=(ConstantNullspace(), ConstantNullspace()))
+    inner = MultiBlockSystem(th.n_v, th.n_v, {(0, 0): th.M_v}, {(0, 0): sp.csr_matrix(D.T)},
+                             {(0, 0): D}, {(0, 0): sp.csr_matrix((-1.0 / beta) * th.M_v)},
+                             nullspace_0=(nsv,), nullspace_1=(nsv,))
+    comm = MultiBlockSystem(th.n_p, th.n_p, {(0, 0): th.M_p}, {(0, 0): sp.csr_matrix(D_p.T)},
+                            {(0, 0): D_p}, {(0, 0): sp.csr_matrix((-1.0 / beta) * th.M_p)})
+    mass, schur, kp = (20, 0.25, 1.5625), (40, 0.02, 2.2), (30, 0.02, 2.2)
+    mp = (20,) + tuple(p["lambda_p_bounds"])
+    inner_pc = SchurPC(kind="stationary", M=th.M_v, beta=beta, bc_nodes=th.boundary_v,
+                       mass=ChebSpec(*mass), schur=ChebSpec(*schur))
+    gpc = StokesPC(inner=inner, inner_pc=inner_pc, commutator=comm, B=th.B, K_p=th.K_p,
+                   M_p=th.M_p, kp=ChebSpec(*kp), mp=ChebSpec(*mp))
+    opc = ko.pc_stationary_incompressible(th.M_v, D, th.B, th.M_p, th.K_p, D_p, beta,
+                                          th.boundary_v, ko.ChebSpec(*mass), ko.ChebSpec(*schur),
+                                          ko.ChebSpec(*kp), ko.ChebSpec(*mp))
+    osys = ko.OracleSystem(th.n_v, th.n_p, *blocks, n_blocks_00=2, n_blocks_11=2,
+                           nullspace_0=(ko.DirichletBCNullspace(th.boundary_v),) * 2,
+                           nullspace_1=(ko.ConstantNullspace(), ko.ConstantNullspace()))
+    return outer, gpc, osys, opc
+
+
+def test_stokes_control_operator_and_preconditioner_parity():
+    """SURVEY 8f-1, stationary: rectangular divergence blocks, ConstantNullspace on the
+    pressures, nested velocity solve and pressure Schur complement (control.py:802-1110)."""
+    p = kat.kat_stationary_incompressible()
+    outer, gpc, osys, opc = _stokes_systems(p)
+    x = common.rng_vector(osys.N)
+    assert common.rel_err(outer.mult(x), osys.mult(x)) < 1e-13
+    # the nested 5-iteration GMRES amplifies round-off like any Krylov iterate comparison
+    assert common.rel_err(outer.pc_apply(x, gpc), osys.pc_apply(opc, x)) < 1e-8
+
+
+def test_kat_stationary_incompressible():
+    """test/test_control.py:232-358 through the GPU path."""
+    p = kat.kat_stationary_incompressible()
+    th = p["th"]
+    outer, gpc, _, _ = _stokes_systems(p)
+    u0, u1 = np.zeros((2, th.n_v)), np.zeros((2, th.n_p))
+    res = outer.solve(u0, u1, p["b_0"], p["b_1"], solver_parameters=p["solver_parameters"],
+                      pc_fn=gpc)
+    assert res.reason > 0
+
+    def l2(M, e):
+        return np.sqrt(abs(e @ (M @ e)))
+
+    def demean(M, q):
+        return q - (np.ones_like(q) @ (M @ q))
+    assert l2(th.M_v, u0[0] - p["v_ref"]) < 1.0e-13
+    assert l2(th.M_v, u0[1] - p["z_ref"]) < 1.0e-13
+    assert l2(th.M_p, demean(th.M_p, u1[1]) - demean(th.M_p, p["p_ref"])) < 5.0e-13   # see
+    assert l2(th.M_p, demean(th.M_p, u1[0]) - demean(th.M_p, p["mu_ref"])) < 1.0e-13  # oracle KAT
