@@ -35,7 +35,7 @@ class PcDesc(C.Structure):
 
 
 class PcStokesDesc(C.Structure):
-    _fields_ = [("n_p_blocks", C.c_int), ("nv", C.c_int64), ("np", C.c_int64),
+    _fields_ = [("n_p_blocks", C.c_int), ("cn", C.c_int), ("nv", C.c_int64), ("np", C.c_int64),
                 ("b_scale", C.c_double), ("post_scale", C.c_double),
                 ("b_indptr", c_i32p), ("b_indices", c_i32p), ("b_values", c_f64p),
                 ("kp_indptr", c_i32p), ("kp_indices", c_i32p), ("kp_values", c_f64p),

@@ -17,7 +17,7 @@ from typing import Sequence
 
 import scipy.sparse as sp
 
-__all__ = ["instationary_blocks", "stationary_blocks"]
+__all__ = ["instationary_blocks", "stationary_blocks", "instationary_incompressible_blocks"]
 
 
 def _csr(A):
@@ -110,3 +110,46 @@ def instationary_blocks(M, K: Sequence, tau: float, beta: float, n_t: int,
             b01[(i, i + 1)] = comb(h, i + 1, -1.0, transpose=True)
             b11[(i, i + 1)] = mass(-h / beta)
     return b00, b01, b10, b11, m
+
+
+def instationary_incompressible_blocks(M_v, K_v, B, M_p, K_p, tau: float, beta: float,
+                                       n_t: int, CN: bool, *, share: bool = True):
+    """Block dicts of ``Instationary.incompressible_linear_solve``
+    (``control/control.py:3750-3957``) for Stokes control.
+
+    Returns a dict with
+
+    * ``outer``: ``(block_00, block_01, block_10, block_11)`` over ``2m`` velocity-space and
+      ``2m`` pressure-space blocks -- ``block_00`` is the velocity KKT system flattened to
+      ``[v_0..v_{m-1}, zeta_0..zeta_{m-1}]`` (``:3793-3829`` BE, ``:3840-3895`` CN),
+      ``block_01/10[(i, i)] = tau B^T / tau B`` (``:3750-3770``), ``block_11`` empty;
+    * ``inner``: the velocity KKT dicts ``block_**_int`` (the heat-type system on ``M_v, K_v``);
+    * ``commutator``: the pressure-space dicts ``block_**_int_p`` (the same construction on
+      ``M_p, K_p``);
+    * ``m``: blocks per variable (``n_t`` BE, ``n_t - 1`` CN).
+
+    ``K_v`` / ``K_p`` are the forward operator assembled on the velocity / pressure space
+    (``construct_D_v`` at ``:3779-3785``), one matrix or one per time level.
+    """
+    i00, i01, i10, i11, m = instationary_blocks(M_v, K_v, tau, beta, n_t, CN, share=share)
+    c00, c01, c10, c11, _ = instationary_blocks(M_p, K_p, tau, beta, n_t, CN, share=share)
+    n = 2 * m
+    b00 = {(i, j): None for i in range(n) for j in range(n)}
+    for (i, j), A in i00.items():
+        b00[(i, j)] = A
+    for (i, j), A in i01.items():
+        b00[(i, m + j)] = A
+    for (i, j), A in i10.items():
+        b00[(m + i, j)] = A
+    for (i, j), A in i11.items():
+        b00[(m + i, m + j)] = A
+    tB = _csr(tau * sp.csr_matrix(B))
+    tBT = _csr(tB.T)
+    b01 = {(i, j): None for i in range(n) for j in range(n)}
+    b10 = dict(b01)
+    b11 = dict(b01)
+    for i in range(n):
+        b01[(i, i)] = _own(tBT, share)
+        b10[(i, i)] = _own(tB, share)
+    return {"outer": (b00, b01, b10, b11), "inner": (i00, i01, i10, i11),
+            "commutator": (c00, c01, c10, c11), "m": m}

@@ -160,6 +160,7 @@ class StokesPC : public PcBase {
    private:
     System &S_, &inner_, &comm_;
     int n_ = 1;   // pressure blocks per variable
+    bool cn_ = false;
     int64_t nv_ = 0, np_ = 0;
     double sB_ = 1.0, s2_ = 1.0;
     int kp_its_ = 0, mp_its_ = 0;

@@ -116,6 +116,7 @@ StokesPC::StokesPC(System &outer, System &inner, System &commutator, const kkt_p
     if (outer.device != inner.device || outer.device != commutator.device)
         fail(KKT_ERR_ARG, "all three systems must live on one GPU");
     n_ = d.n_p_blocks;
+    cn_ = d.cn != 0;
     nv_ = d.nv;
     np_ = d.np;
     if (n_ < 1 || outer.n0 != 2 * n_ || outer.n1 != 2 * n_ || outer.nx0 != nv_ || outer.nx1 != np_)
@@ -160,9 +161,13 @@ StokesPC::StokesPC(System &outer, System &inner, System &commutator, const kkt_p
             op.t[0].vals = B_.vals;
             op.t[0].x = vabs(out_ + (int64_t)k * nv_);
             op.y = vabs(h_ + (int64_t)k * np_);
-            op.ca = s2_ * sB_;
-            op.cz = -s2_;
-            op.z = vabs(in_ + n0 + (int64_t)k * np_);
+            if (cn_) {   // the time transforms come between the product and the subtraction
+                op.ca = sB_;
+            } else {
+                op.ca = s2_ * sB_;
+                op.cz = -s2_;
+                op.z = vabs(in_ + n0 + (int64_t)k * np_);
+            }
             ops.push_back(op);
         }
         lin_.push_back(upload_launch(P, ops));
@@ -193,6 +198,15 @@ void StokesPC::run() {
     HIPCHK(hipStreamSynchronize(inner_.stream));
     for (const RowLaunch &L : lin_)
         launch_rowops(st, L.d_ops, L.nops, L.max_slices, L.R, B, 1, L.uniform_w);
+    if (cn_) {   // control.py:4407-4428
+        const int64_t half = (int64_t)n_ * np_;
+        launch_time_transform(st, h_, h_, 2, n_, np_, nullptr, nullptr);
+        launch_time_transform(st, h_ + half, h_ + half, 1, n_, np_, nullptr, nullptr);
+        launch_axpby(st, h_, -1.0, in_ + n0, 1.0, 2 * half);
+        launch_axpby(st, h_, 0.0, in_ + n0, s2_, 2 * half);
+        launch_time_transform(st, h_, h_, 4, n_, np_, nullptr, nullptr);
+        launch_time_transform(st, h_ + half, h_ + half, 3, n_, np_, nullptr, nullptr);
+    }
     for (const RowLaunch &L : kp_steps_)
         launch_rowops(st, L.d_ops, L.nops, L.max_slices, L.R, B, 1, L.uniform_w);
     // g = C m: the pressure-space commutator block system (control.py:1056-1067, 4625-4665)

@@ -255,3 +255,98 @@ def unit_square_q2q1(n: int) -> TaylorHoodDiscretisation:
     nb = sd.boundary
     boundary_v = np.concatenate([nb, nb + sd.n_dofs]).astype(np.int32)
     return TaylorHoodDiscretisation(M_v, K_v, B, M_p, K_p, sd.coords, coords_p, boundary_v)
+
+
+# ------------------------------------------------------- Taylor-Hood (P2-P1, triangles)
+
+def rectangle_p2p1(nx: int, ny: int, lx: float = 1.0, ly: float = 1.0) -> TaylorHoodDiscretisation:
+    """P2 velocity / P1 pressure on the right-diagonal triangulation of ``[0,lx] x [0,ly]``
+    (``RectangleMesh(nx, ny, lx, ly)``, the spaces of the reference's Stokes-control tests,
+    ``test/test_control.py:3546-3560``).  P2 dofs are the points of the ``(2nx+1) x (2ny+1)``
+    grid, P1 dofs the mesh vertices, both in lexicographic (y-major) order; the velocity
+    vector is component-major."""
+    nvx, nvy = 2 * nx + 1, 2 * ny + 1
+    npx = nx + 1
+
+    def vid(i, j):          # P2 grid index
+        return j * nvx + i
+
+    def pid(i, j):
+        return j * npx + i
+    ii, jj = np.meshgrid(np.arange(nx), np.arange(ny), indexing="xy")
+    ii, jj = ii.ravel(), jj.ravel()
+    hx, hy = lx / nx, ly / ny
+    # two triangles per cell: (00, 10, 11) and (00, 11, 01); local P2 order:
+    # vertices 0,1,2 then midpoints of edges (0,1), (1,2), (0,2)
+    tri_v, tri_p, tri_x = [], [], []
+    for (a, b, c) in (((0, 0), (1, 0), (1, 1)), ((0, 0), (1, 1), (0, 1))):
+        verts = [a, b, c]
+        mids = [((a[0] + b[0]), (a[1] + b[1])), ((b[0] + c[0]), (b[1] + c[1])),
+                ((a[0] + c[0]), (a[1] + c[1]))]
+        v_idx = [vid(2 * ii + 2 * v[0], 2 * jj + 2 * v[1]) for v in verts] + \
+                [vid(2 * ii + m[0], 2 * jj + m[1]) for m in mids]
+        p_idx = [pid(ii + v[0], jj + v[1]) for v in verts]
+        xy = [np.stack([(ii + v[0]) * hx, (jj + v[1]) * hy], 1) for v in verts]
+        tri_v.append(np.stack(v_idx, 1))
+        tri_p.append(np.stack(p_idx, 1))
+        tri_x.append(np.stack(xy, 1))
+    V = np.concatenate(tri_v, 0)            # (ne, 6)
+    Pn = np.concatenate(tri_p, 0)           # (ne, 3)
+    X = np.concatenate(tri_x, 0)            # (ne, 3, 2)
+    ne = len(V)
+    # degree-4 quadrature on the reference triangle (6 points), barycentric
+    a1, a2 = 0.445948490915965, 0.091576213509771
+    w1, w2 = 0.223381589678011, 0.109951743655322
+    lam = np.array([[a1, a1, 1 - 2 * a1], [a1, 1 - 2 * a1, a1], [1 - 2 * a1, a1, a1],
+                    [a2, a2, 1 - 2 * a2], [a2, 1 - 2 * a2, a2], [1 - 2 * a2, a2, a2]])
+    wq = 0.5 * np.array([w1, w1, w1, w2, w2, w2])
+    # gradients of barycentric coordinates per element
+    A = np.concatenate([np.ones((ne, 3, 1)), X], axis=2)
+    Ainv = np.linalg.inv(A)
+    glam = np.transpose(Ainv[:, 1:, :], (0, 2, 1))          # (ne, 3, 2)
+    detJ = np.abs(np.linalg.det(A))                         # 2 * area
+    l = lam                                                 # (nq, 3)
+    phi = np.stack([l[:, 0] * (2 * l[:, 0] - 1), l[:, 1] * (2 * l[:, 1] - 1),
+                    l[:, 2] * (2 * l[:, 2] - 1), 4 * l[:, 0] * l[:, 1],
+                    4 * l[:, 1] * l[:, 2], 4 * l[:, 0] * l[:, 2]], 1)     # (nq, 6)
+    # d phi / d lambda_k, (nq, 6, 3)
+    dphi = np.zeros((len(l), 6, 3))
+    for k in range(3):
+        dphi[:, k, k] = 4 * l[:, k] - 1
+    dphi[:, 3, 0], dphi[:, 3, 1] = 4 * l[:, 1], 4 * l[:, 0]
+    dphi[:, 4, 1], dphi[:, 4, 2] = 4 * l[:, 2], 4 * l[:, 1]
+    dphi[:, 5, 0], dphi[:, 5, 2] = 4 * l[:, 2], 4 * l[:, 0]
+    gphi = np.einsum("qak,ekd->eqad", dphi, glam)           # (ne, nq, 6, 2)
+    W = wq[None, :] * detJ[:, None]                         # (ne, nq)
+    Me = np.einsum("eq,qa,qb->eab", W, phi, phi)
+    Ke = np.einsum("eq,eqad,eqbd->eab", W, gphi, gphi)
+    Bxe = -np.einsum("eq,qc,eqa->eca", W, l, gphi[..., 0])  # (ne, 3, 6)
+    Bye = -np.einsum("eq,qc,eqa->eca", W, l, gphi[..., 1])
+    Mpe = np.einsum("eq,qc,qd->ecd", W, l, l)
+    Kpe = np.einsum("e,ecx,edx->ecd", 0.5 * detJ, glam, glam)
+    n2, n1 = nvx * nvy, npx * (ny + 1)
+
+    def asm(Ee, rows, cols, shape):
+        r = np.repeat(rows, cols.shape[1], axis=1).ravel()
+        c = np.tile(cols, (1, rows.shape[1])).ravel()
+        return _canonical_csr(sp.coo_matrix((Ee.ravel(), (r, c)), shape=shape))
+    M2 = asm(Me, V, V, (n2, n2))
+    K2 = asm(Ke, V, V, (n2, n2))
+    Bx = asm(Bxe, Pn, V, (n1, n2))
+    By = asm(Bye, Pn, V, (n1, n2))
+    M_p = asm(Mpe, Pn, Pn, (n1, n1))
+    K_p = asm(Kpe, Pn, Pn, (n1, n1))
+    I2 = sp.identity(2, format="csr")
+    xs, ys = np.linspace(0, lx, nvx), np.linspace(0, ly, nvy)
+    XX, YY = np.meshgrid(xs, ys, indexing="xy")
+    coords_v = np.stack([XX.ravel(), YY.ravel()], 1)
+    xp, yp = np.linspace(0, lx, npx), np.linspace(0, ly, ny + 1)
+    XP, YP = np.meshgrid(xp, yp, indexing="xy")
+    coords_p = np.stack([XP.ravel(), YP.ravel()], 1)
+    onb = ((coords_v[:, 0] == 0) | (coords_v[:, 0] == xs[-1]) | (coords_v[:, 1] == 0)
+           | (coords_v[:, 1] == ys[-1]))
+    nb = np.flatnonzero(onb)
+    return TaylorHoodDiscretisation(
+        _canonical_csr(sp.kron(I2, M2)), _canonical_csr(sp.kron(I2, K2)),
+        _canonical_csr(sp.hstack([Bx, By])), M_p, K_p, coords_v, coords_p,
+        np.concatenate([nb, nb + n2]).astype(np.int32))

@@ -98,8 +98,8 @@ class SchurPC:
 class StokesPC:
     """Built-in preconditioner of the incompressible control systems, run on the GPU
     (``kkt_set_pc_stokes``): the ``pc_fn`` closures of
-    ``Stationary.incompressible_linear_solve`` (``control/control.py:986-1085``) and the BE
-    branch of ``Instationary.incompressible_linear_solve`` (``control.py:4515-4687``).
+    ``Stationary.incompressible_linear_solve`` (``control/control.py:986-1085``) and of
+    ``Instationary.incompressible_linear_solve`` (BE ``control.py:4515-4687``, CN ``:4318-4513``).
 
     ``inner``: the velocity KKT ``MultiBlockSystem``; ``inner_pc``: its ``SchurPC``;
     ``commutator``: the pressure-space block system ``block_**_int_p``; ``B, K_p, M_p``:
@@ -117,6 +117,7 @@ class StokesPC:
     b_scale: float = 1.0
     post_scale: float = 1.0
     inner_its: int = 5            # control.py:1005-1010
+    cn: bool = False              # Crank-Nicolson branch (control.py:4318-4513)
 
 
 class KSPResult:
@@ -345,7 +346,7 @@ class MultiBlockSystem:
                                               int(pc_fn.inner_its)))
             mats = [_as_csr(A) for A in (pc_fn.B, pc_fn.K_p, pc_fn.M_p)]
             d = _lib.PcStokesDesc(
-                n_p_blocks=int(pc_fn.n_p_blocks), nv=self._nx0, np=self._nx1,
+                n_p_blocks=int(pc_fn.n_p_blocks), cn=int(bool(pc_fn.cn)), nv=self._nx0, np=self._nx1,
                 b_scale=float(pc_fn.b_scale), post_scale=float(pc_fn.post_scale),
                 kp_its=int(pc_fn.kp.its), kp_emin=float(pc_fn.kp.emin),
                 kp_emax=float(pc_fn.kp.emax), mp_its=int(pc_fn.mp.its),

@@ -142,15 +142,17 @@ typedef struct kkt_pc_desc {
 int kkt_set_pc_schur(kkt_handle h, const kkt_pc_desc *desc);
 
 /* Preconditioner of the incompressible control systems: the pc_fn closures of
- * Stationary.incompressible_linear_solve (control.py:986-1085) and the BE branch of
- * Instationary.incompressible_linear_solve (control.py:4515-4687).  `h` is the outer system
+ * Stationary.incompressible_linear_solve (control.py:986-1085) and of
+ * Instationary.incompressible_linear_solve (BE control.py:4515-4687, CN control.py:4318-4513).  `h` is the outer system
  * (variable 0 = velocity blocks v then zeta, variable 1 = pressure blocks mu then p); `inner`
  * is the velocity KKT system with its own preconditioner and KSP options already set
  * (the reference runs 5 GMRES iterations, control.py:1005-1010); `commutator` is the
  * pressure-space block system block_**_int_p (control.py:976-984, 3818-3820).  Both handles
  * must stay alive while `h` uses them.  B = -(div v, q) is the unscaled divergence block. */
 typedef struct kkt_pc_stokes_desc {
-    int n_p_blocks;          /* pressure blocks per variable (1 stationary, n_t BE) */
+    int n_p_blocks;          /* pressure blocks per variable (1 stationary, n_t BE, n_t-1 CN) */
+    int cn;                  /* 1: Crank-Nicolson branch -- T_2 / T_1 on tau B u_0 before b_1 is
+                                subtracted and their inverses after the scaling (control.py:4407-4428) */
     int64_t nv, np;          /* dofs of one velocity / pressure block */
     double b_scale;          /* tau (instationary, control.py:4577) or 1 */
     double post_scale;       /* 1 / tau^2 (control.py:4596-4601) or 1 */

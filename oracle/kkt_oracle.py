@@ -782,3 +782,74 @@ def pc_stationary_incompressible(M_v, D_v, B, M_p, K_p, D_p, beta, nodes_v, mass
         u_1[0] = _inner_solve(M_p, mp_spec, g0)
         u_1[1] = _inner_solve(M_p, mp_spec, g1)
     return pc_fn
+
+
+# ---------------------------------------------- incompressible (Stokes) control, instationary
+
+
+def pc_instationary_incompressible(M_v, inner_blocks, B, M_p, K_p, comm_blocks, n_t, tau, beta,
+                                   nodes_v, mass_spec, schur_spec, kp_spec, mp_spec, CN=False,
+                                   inner_its=5, epsilon=1.0e-3):
+    """``pc_fn`` of ``Instationary.incompressible_linear_solve``: BE branch
+    ``control/control.py:4515-4687``, CN branch ``:4318-4513``.
+
+    ``inner_its`` GMRES iterations on the velocity KKT system with the instationary block-Schur
+    preconditioner (``:4524-4553``), ``h = tau B u_0 - b_1`` scaled by ``1/tau^2``
+    (``:4571-4601``; CN: ``T_2``/``T_1`` before the subtraction and their inverses after the
+    scaling, ``:4407-4428``), ``K_p`` solve per block (``:4603-4619``), product with the
+    pressure-space block system ``block_**_int_p`` (``:4625-4665``), ``M_p`` solve per block
+    (``:4670-4684``)."""
+    i00, i01, i10, i11 = inner_blocks
+    c00, c01, c10, c11 = comm_blocks
+    m = n_t - 1 if CN else n_t
+    nv = M_v.shape[0]
+    npr = M_p.shape[0]
+    ns = tuple(DirichletBCNullspace(nodes_v) for _ in range(m))
+    inner = OracleSystem(nv, nv, i00, i01, i10, i11, n_blocks_00=m, n_blocks_11=m,
+                         nullspace_0=ns, nullspace_1=ns, CN=CN)
+    if CN:
+        inner_pc = pc_instationary_CN(M_v, i01, i10, n_t, tau, beta, nodes_v, mass_spec,
+                                      schur_spec)
+    else:
+        inner_pc = pc_instationary_BE(M_v, i01, i10, n_t, tau, beta, nodes_v, mass_spec,
+                                      schur_spec, epsilon=epsilon)
+    inner_sp = {"preconditioner": True, "linear_solver": "gmres",
+                "maximum_iterations": inner_its, "relative_tolerance": 0.0,
+                "absolute_tolerance": 0.0, "monitor_convergence": False}
+    B = sp.csr_matrix(B)
+    K_p = sp.csr_matrix(K_p)
+    M_p = sp.csr_matrix(M_p)
+
+    def pc_fn(u_0, u_1, b_0, b_1):
+        v = np.zeros((m, nv))
+        z = np.zeros((m, nv))
+        inner.solve(v, z, b_0[:m], b_0[m:], solver_parameters=inner_sp, pc_fn=inner_pc)
+        u_0[:m], u_0[m:] = v, z
+        h0 = np.stack([tau * (B @ v[i]) for i in range(m)])
+        h1 = np.stack([tau * (B @ z[i]) for i in range(m)])
+        if CN:
+            h0, h1 = apply_T_2(h0), apply_T_1(h1)
+        h0 = (h0 - b_1[:m]) * (1.0 / tau**2)
+        h1 = (h1 - b_1[m:]) * (1.0 / tau**2)
+        if CN:
+            h0, h1 = apply_T_2_inv(h0), apply_T_1_inv(h1)
+        m0 = np.stack([_inner_solve(K_p, kp_spec, h0[i]) for i in range(m)])
+        m1 = np.stack([_inner_solve(K_p, kp_spec, h1[i]) for i in range(m)])
+        g0 = np.zeros((m, npr))
+        g1 = np.zeros((m, npr))
+        for (i, j), A in c00.items():
+            if A is not None:
+                g0[i] += A @ m0[j]
+        for (i, j), A in c01.items():
+            if A is not None:
+                g0[i] += A @ m1[j]
+        for (i, j), A in c10.items():
+            if A is not None:
+                g1[i] += A @ m0[j]
+        for (i, j), A in c11.items():
+            if A is not None:
+                g1[i] += A @ m1[j]
+        for i in range(m):
+            u_1[i] = _inner_solve(M_p, mp_spec, g0[i])
+            u_1[m + i] = _inner_solve(M_p, mp_spec, g1[i])
+    return pc_fn

@@ -60,3 +60,60 @@ def rng_vector(n, seed=SEED):
 
 def rel_err(a, b):
     return np.linalg.norm(np.ravel(a) - np.ravel(b)) / max(np.linalg.norm(np.ravel(b)), 1e-300)
+
+
+# ------------------------------------------ instationary Stokes control
+
+STOKES_SPECS = dict(mass=(20, 0.3, 1.9), schur=(30, 0.02, 2.2), kp=(30, 0.02, 2.2),
+                    mp=(20, 0.25, 2.25))
+
+
+def stokes_problem(n=4, n_t=4, beta=1.0e-2, T=2.0, CN=False, share=True):
+    """Config-3-shaped system: P2-P1 on ``RectangleMesh(n, n, 2, 2)`` (BASELINE configs[2])."""
+    from control_amd.blocks import instationary_incompressible_blocks
+    from control_amd.fem import rectangle_p2p1
+    th = rectangle_p2p1(n, n, 2.0, 2.0)
+    tau = T / (n_t - 1.0)
+    bl = instationary_incompressible_blocks(th.M_v, th.K_v, th.B, th.M_p, th.K_p, tau, beta,
+                                            n_t, CN, share=share)
+    return dict(th=th, tau=tau, beta=beta, n_t=n_t, CN=CN, m=bl["m"], blocks=bl)
+
+
+def stokes_oracle(p, specs=STOKES_SPECS):
+    from oracle import kkt_oracle as ko
+    th, m, CN, bl = p["th"], p["m"], p["CN"], p["blocks"]
+    kw = dict(sub_n_blocks_00_0=m, sub_n_blocks_11_0=m) if CN else {}
+    osys = ko.OracleSystem(th.n_v, th.n_p, *bl["outer"], n_blocks_00=2 * m, n_blocks_11=2 * m,
+                           nullspace_0=tuple(ko.DirichletBCNullspace(th.boundary_v)
+                                             for _ in range(2 * m)),
+                           nullspace_1=tuple(ko.ConstantNullspace() for _ in range(2 * m)),
+                           CN=CN, **kw)
+    opc = ko.pc_instationary_incompressible(
+        th.M_v, bl["inner"], th.B, th.M_p, th.K_p, bl["commutator"], p["n_t"], p["tau"],
+        p["beta"], th.boundary_v, ko.ChebSpec(*specs["mass"]), ko.ChebSpec(*specs["schur"]),
+        ko.ChebSpec(*specs["kp"]), ko.ChebSpec(*specs["mp"]), CN=CN)
+    return osys, opc
+
+
+def stokes_gpu(p, specs=STOKES_SPECS):
+    """Outer system, velocity KKT system and pressure commutator on the GPU + the StokesPC."""
+    from control_amd.multiblock import (ChebSpec, ConstantNullspace, DirichletBCNullspace,
+                                        MultiBlockSystem, SchurPC, StokesPC)
+    th, m, CN, bl = p["th"], p["m"], p["CN"], p["blocks"]
+    nsv = DirichletBCNullspace(th.boundary_v)
+    kw = dict(sub_n_blocks_00_0=m, sub_n_blocks_11_0=m) if CN else {}
+    outer = MultiBlockSystem(th.n_v, th.n_p, *bl["outer"], n_blocks_00=2 * m,
+                             n_blocks_11=2 * m, nullspace_0=(nsv,) * (2 * m),
+                             nullspace_1=tuple(ConstantNullspace() for _ in range(2 * m)),
+                             CN=CN, **kw)
+    inner = MultiBlockSystem(th.n_v, th.n_v, *bl["inner"], n_blocks_00=m, n_blocks_11=m,
+                             nullspace_0=(nsv,) * m, nullspace_1=(nsv,) * m, CN=CN)
+    # the commutator product is a plain block product (control.py:4625-4665): no transforms
+    comm = MultiBlockSystem(th.n_p, th.n_p, *bl["commutator"], n_blocks_00=m, n_blocks_11=m)
+    inner_pc = SchurPC(kind="CN" if CN else "BE", M=th.M_v, beta=p["beta"],
+                       bc_nodes=th.boundary_v, mass=ChebSpec(*specs["mass"]),
+                       schur=ChebSpec(*specs["schur"]), n_t=p["n_t"], tau=p["tau"])
+    gpc = StokesPC(inner=inner, inner_pc=inner_pc, commutator=comm, B=th.B, K_p=th.K_p,
+                   M_p=th.M_p, kp=ChebSpec(*specs["kp"]), mp=ChebSpec(*specs["mp"]),
+                   n_p_blocks=m, b_scale=p["tau"], post_scale=1.0 / p["tau"]**2, cn=CN)
+    return outer, gpc
