@@ -123,12 +123,88 @@ def cpu_baseline(p, args):
             "single_thread_sample": f"{out[1][1]} iterations, {out[1][2]:.1f} s"}
 
 
+def bench_stokes(args, world):
+    """BASELINE configs[2] (a parity/measurement case, not the headline line): instationary
+    Stokes control, Taylor-Hood P2-P1 on RectangleMesh(n, n, 2, 2), outer FGMRES(10) with the
+    StokesPC (5 nested GMRES iterations on the velocity KKT system per application).
+    Chebyshev bounds of test/test_control.py:471-472; one GPU (the nested solve is not
+    time-sharded)."""
+    import common
+    from control_amd import _lib
+    if world != 1:
+        raise SystemExit("--workload stokes2d runs on one GPU")
+    n = args.n if args.n != 256 else 128
+    n_t = args.n_t if args.n_t != 64 else 32
+    beta = args.beta if args.beta != 1.0e-4 else 1.0e-3
+    CN = args.scheme == "CN"
+    print("[bench] assembling the synthetic Stokes system", file=sys.stderr, flush=True)
+    p = common.stokes_problem(n=n, n_t=n_t, beta=beta, T=args.T, CN=CN, share=(args.mode == "S"))
+    specs = dict(mass=(20, 0.3924, 2.0598), mp=(20, 0.5, 2.0),
+                 # Jacobi-scaled P2 stiffness: lambda_max = 2.19 (measured with eigsh)
+                 schur=(args.schur_its, args.schur_emin, max(args.schur_emax, 2.25)),
+                 kp=(args.schur_its, args.schur_emin, args.schur_emax))
+    outer, gpc = common.stokes_gpu(p, specs)
+    lib, h = outer._lib, outer.handle
+    outer._set_pc(gpc)
+    info = outer.info()
+    n_local = info["n_local"]
+
+    def dvec(host=None):
+        d = C.c_void_p()
+        outer._ck(lib.kkt_vec_alloc(h, C.byref(d)))
+        if host is not None:
+            outer._ck(lib.kkt_vec_upload(h, d, _lib.f64(host)[1]))
+        return d
+    x = common.rng_vector(n_local)
+    d_x, d_y, d_u = dvec(x), dvec(), dvec()
+    ms = C.c_float()
+    outer._ck(lib.kkt_time_apply(h, d_x, d_y, 5, C.byref(ms)))
+    outer._ck(lib.kkt_time_apply(h, d_x, d_y, args.spmv_reps, C.byref(ms)))
+    spmv_ms = ms.value / args.spmv_reps
+    outer._ck(lib.kkt_time_pc_apply(h, d_x, d_y, 1, C.byref(ms)))
+    outer._ck(lib.kkt_time_pc_apply(h, d_x, d_y, 3, C.byref(ms)))
+    pc_ms = ms.value / 3
+
+    def run(max_it):
+        outer._ck(lib.kkt_vec_upload(h, d_u, _lib.f64(np.zeros(n_local))[1]))
+        outer._ck(lib.kkt_set_krylov(h, 1, -1, 10, 0.0, 0.0, 1e300, max_it))
+        its, reason, nh, rn = C.c_int(), C.c_int(), C.c_int(), C.c_double()
+        outer._ck(lib.kkt_sync(h))
+        t0 = time.perf_counter()
+        outer._ck(lib.kkt_solve_device(h, d_x, d_u, C.byref(its), C.byref(reason),
+                                       C.byref(rn), None, 0, C.byref(nh)))
+        outer._ck(lib.kkt_sync(h))
+        return its.value, time.perf_counter() - t0
+    print(f"[bench] spmv {spmv_ms:.3f} ms, pc {pc_ms:.3f} ms; Krylov leg", file=sys.stderr,
+          flush=True)
+    if args.warmup > 0:
+        run(args.warmup)
+    its, dt = run(args.steps)
+    alg = info["bytes_algorithmic"]
+    achieved = alg / (spmv_ms * 1e-3) / 1e9
+    th = p["th"]
+    print(json.dumps({
+        "metric": "Krylov iterations/s (preconditioned FGMRES(10), all-at-once Stokes-control KKT)",
+        "value": its / dt, "unit": "Krylov iterations/s", "n_gpus": 1, "steps": its,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / its, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": (f"2-D Stokes control, Taylor-Hood P2-P1 {n}x{n}, n_t={n_t}, "
+                                f"beta={beta:g}, T={args.T:g}, {args.scheme}, mode {args.mode}"),
+                   "unknowns": int(n_local), "n_v": int(th.n_v), "n_p": int(th.n_p),
+                   "krylov": "outer fgmres restart 10; inner gmres, 5 iterations per application",
+                   "pc_apply_ms": pc_ms, "kkt_apply_ms": spmv_ms},
+        "roofline": {"kernel": "kkt_spmv_rows (outer Stokes-control operator)", "bound": "hbm",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg, "launch_ms": spmv_ms}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="heat2d", choices=["heat2d", "heat3d"])
+    ap.add_argument("--workload", default="heat2d", choices=["heat2d", "heat3d", "stokes2d"])
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--n_t", type=int, default=64)
     ap.add_argument("--beta", type=float, default=1.0e-4)
@@ -158,6 +234,8 @@ def main():
     from control_amd import _lib
     from control_amd.dist import make_comm
 
+    if args.workload == "stokes2d":
+        return bench_stokes(args, world)
     print("[bench] assembling the synthetic system", file=sys.stderr, flush=True)
     p = build_problem(args)
     comm = make_comm(rank, world, local_rank) if world > 1 else None

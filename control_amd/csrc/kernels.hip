@@ -1141,6 +1141,48 @@ void launch_block_shift(hipStream_t s, double *y, const double *sums, double coe
     hipLaunchKernelGGL(block_shift_kernel, grid, dim3(256), 0, s, y, sums, coef, nx);
 }
 
+// ConstantNullspace on all its blocks at once (preconditioner.py:137-152): sums of block j of
+// `a` (and of `b` when given) by one workgroup each, in a fixed order; then
+// y_j = (y_j + c1_j * sum_a_j) + c2_j * sum_b_j, the two additions the per-block form made.
+__global__ void const_sums_kernel(const ConstJob *__restrict__ jobs, int njobs,
+                                  const double *__restrict__ a, const double *__restrict__ b,
+                                  double *__restrict__ sums) {
+    __shared__ double sh[256];
+    const ConstJob j = jobs[blockIdx.x];
+    const double *xb = (blockIdx.y == 0 ? a : b) + j.off;
+    double acc = 0.0;
+    for (int64_t r = threadIdx.x; r < j.nx; r += 256) acc += xb[r];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[blockIdx.y * njobs + blockIdx.x] = sh[0];
+}
+__global__ void const_shift_kernel(const ConstJob *__restrict__ jobs, int njobs,
+                                   double *__restrict__ y, const double *__restrict__ sums,
+                                   int second) {
+    const ConstJob j = jobs[blockIdx.y];
+    const double s1 = j.c1 * sums[blockIdx.y];
+    const double s2 = second ? (second == 2 ? j.c2_alpha : j.c2_one) * sums[njobs + blockIdx.y] : 0.0;
+    double *yb = y + j.off;
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < j.nx;
+         r += (int64_t)gridDim.x * blockDim.x) {
+        double v = yb[r] + s1;
+        if (second) v += s2;
+        yb[r] = v;
+    }
+}
+void launch_const_correct(hipStream_t s, const ConstJob *d_jobs, int njobs, int64_t max_nx,
+                          double *y, const double *b, int second, double *sums) {
+    if (njobs <= 0) return;
+    hipLaunchKernelGGL(const_sums_kernel, dim3(njobs, second ? 2 : 1), dim3(256), 0, s, d_jobs,
+                       njobs, y, b, sums);
+    hipLaunchKernelGGL(const_shift_kernel, dim3(grid_for(max_nx, 256, 64), njobs), dim3(256), 0,
+                       s, d_jobs, njobs, y, sums, second);
+}
+
 // -------------------------------------------------------------------------- reductions
 
 __device__ __forceinline__ double wave_sum(double v) {

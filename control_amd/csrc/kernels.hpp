@@ -106,6 +106,11 @@ void launch_time_transform(hipStream_t s, double *y, const double *x, int kind, 
 // y_k += shift_k for `n` blocks where shift_k = coef * sums[k] (ConstantNullspace)
 void launch_block_shift(hipStream_t s, double *y, const double *sums, double coef, int n,
                         int64_t nx);
+// ConstantNullspace on every block that carries one, in two launches:
+// y_j -= mean(y_j); second == 1: y_j += mean(b_j); second == 2: y_j += alpha_j * mean(b_j)
+struct ConstJob { int64_t off, nx; double c1, c2_one, c2_alpha; };
+void launch_const_correct(hipStream_t s, const ConstJob *d_jobs, int njobs, int64_t max_nx,
+                          double *y, const double *b, int second, double *sums);
 void launch_block_sums(hipStream_t s, const double *x, double *sums, int n, int64_t nx,
                        double *scratch);
 

@@ -73,36 +73,16 @@ static void per_var(const System &S, double *y, const double *x, const double *m
     }
 }
 
-template <class F>
-static void for_const_blocks(System &S, F f) {
-    for (int var = 0; var < 2; ++var) {
-        const int nloc = var == 0 ? S.n0_loc : S.n1_loc;
-        const int64_t nxv = var == 0 ? S.nx0 : S.nx1;
-        for (int il = 0; il < nloc; ++il) {
-            const int g = var == 0 ? S.global_row(0, il) : S.n0 + S.global_row(1, il);
-            if (S.nullspaces[g].kind == 2) f(S.local_offset(var, il), nxv, S.nullspaces[g]);
-        }
-    }
-}
-
 void System::ns_project(double *y, const double *x) {
     per_var(*this, y, x, nullptr, d_mask_jobs);
     if (any_const_ns)
-        for_const_blocks(*this, [&](int64_t off, int64_t nxv, const NullspaceSpec &) {
-            launch_block_sums(stream, y + off, d_sums, 1, nxv, nullptr);
-            launch_block_shift(stream, y + off, d_sums, -1.0 / (double)nxv, 1, nxv);
-        });
+        launch_const_correct(stream, d_const_jobs, n_const_jobs, const_max_nx, y, nullptr, 0, d_sums);
 }
 
 void System::ns_pc_post(double *y, const double *u, const double *b) {
     per_var(*this, y, u, b, d_mask_jobs_one);
     if (any_const_ns)
-        for_const_blocks(*this, [&](int64_t off, int64_t nxv, const NullspaceSpec &) {
-            launch_block_sums(stream, y + off, d_sums, 1, nxv, nullptr);
-            launch_block_shift(stream, y + off, d_sums, -1.0 / (double)nxv, 1, nxv);
-            launch_block_sums(stream, b + off, d_sums, 1, nxv, nullptr);
-            launch_block_shift(stream, y + off, d_sums, 1.0 / (double)nxv, 1, nxv);
-        });
+        launch_const_correct(stream, d_const_jobs, n_const_jobs, const_max_nx, y, b, 1, d_sums);
 }
 
 // y = P pc_fn(P x) + (I - P) x   (preconditioner.py:562-656)

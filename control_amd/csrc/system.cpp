@@ -49,6 +49,7 @@ System::~System() {
     F(d_xc);
     F(d_tmp_y);
     F(d_sums);
+    F(d_const_jobs);
     F(d_halo_x0_lo);
     F(d_halo_x1_hi);
     F(d_halo_r0_hi);
@@ -504,7 +505,21 @@ void System::finalize() {
     }
     if (any_const_ns) {
         d_xc = new_vec();
-        d_sums = dev_alloc<double>(n0_loc + n1_loc);
+        std::vector<ConstJob> cj;
+        for (int var = 0; var < 2; ++var) {
+            const int nloc = var == 0 ? n0_loc : n1_loc;
+            const int64_t nxv = var == 0 ? nx0 : nx1;
+            for (int il = 0; il < nloc; ++il) {
+                const int g = var == 0 ? global_row(0, il) : n0 + global_row(1, il);
+                if (nullspaces[g].kind != 2) continue;
+                cj.push_back({local_offset(var, il), nxv, -1.0 / (double)nxv, 1.0 / (double)nxv,
+                              nullspaces[g].alpha / (double)nxv});
+                const_max_nx = std::max(const_max_nx, nxv);
+            }
+        }
+        n_const_jobs = (int)cj.size();
+        d_const_jobs = dev_upload(cj.data(), cj.size());
+        d_sums = dev_alloc<double>(2 * cj.size());
     }
     if (sharded) {
         d_halo_x0_lo = dev_alloc<double>(nx0);
@@ -544,17 +559,8 @@ void System::apply(const double *d_x, double *d_y) {
     if (any_const_ns) {
         // x_c = x - mean(x) on ConstantNullspace blocks (preconditioner.py:145-146, 384-393)
         launch_copy(stream, d_xc, d_x, n_local);
-        for (int var = 0; var < 2; ++var) {
-            const int nloc = var == 0 ? n0_loc : n1_loc;
-            const int64_t nxv = var == 0 ? nx0 : nx1;
-            for (int il = 0; il < nloc; ++il) {
-                const int g = var == 0 ? global_row(0, il) : n0 + global_row(1, il);
-                if (nullspaces[g].kind != 2) continue;
-                double *xb = d_xc + local_offset(var, il);
-                launch_block_sums(stream, xb, d_sums, 1, nxv, nullptr);
-                launch_block_shift(stream, xb, d_sums, -1.0 / (double)nxv, 1, nxv);
-            }
-        }
+        launch_const_correct(stream, d_const_jobs, n_const_jobs, const_max_nx, d_xc, nullptr, 0,
+                             d_sums);
         xin = d_xc;
     }
     if (sharded) comm_exchange_x_halos(*this, xin);
@@ -588,20 +594,7 @@ void System::apply(const double *d_x, double *d_y) {
     }
     if (any_const_ns) {
         // y -= mean(y); y += alpha * mean(x)  (preconditioner.py:137-152)
-        for (int var = 0; var < 2; ++var) {
-            const int nloc = var == 0 ? n0_loc : n1_loc;
-            const int64_t nxv = var == 0 ? nx0 : nx1;
-            for (int il = 0; il < nloc; ++il) {
-                const int g = var == 0 ? global_row(0, il) : n0 + global_row(1, il);
-                if (nullspaces[g].kind != 2) continue;
-                double *yb = d_y + local_offset(var, il);
-                const double *xb = d_x + local_offset(var, il);
-                launch_block_sums(stream, yb, d_sums, 1, nxv, nullptr);
-                launch_block_shift(stream, yb, d_sums, -1.0 / (double)nxv, 1, nxv);
-                launch_block_sums(stream, xb, d_sums, 1, nxv, nullptr);
-                launch_block_shift(stream, yb, d_sums, nullspaces[g].alpha / (double)nxv, 1, nxv);
-            }
-        }
+        launch_const_correct(stream, d_const_jobs, n_const_jobs, const_max_nx, d_y, d_x, 2, d_sums);
     }
 }
 

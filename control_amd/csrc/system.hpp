@@ -149,6 +149,9 @@ struct System {
     double *d_xc = nullptr;           // ConstantNullspace-corrected copy of x
     double *d_tmp_y = nullptr;        // raw rows before the CN transform
     double *d_sums = nullptr;
+    ConstJob *d_const_jobs = nullptr;   // ConstantNullspace blocks of this handle
+    int n_const_jobs = 0;
+    int64_t const_max_nx = 0;
     // halos (time-sharded): x0 block lo-1, x1 block hi; CN raw rows rho0_hi, rho1_{lo-1}
     double *d_halo_x0_lo = nullptr, *d_halo_x1_hi = nullptr;
     double *d_halo_r0_hi = nullptr, *d_halo_r1_lo = nullptr;

@@ -48,7 +48,13 @@ class RcclComm(_CommBase):
     def __init__(self, rank, world, rendezvous_dir=None, timeout=300.0):
         super().__init__(rank, world)
         if rendezvous_dir is None:
-            key = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+            # launcher pid + its start time (a recycled pid must not find stale files)
+            try:
+                with open(f"/proc/{os.getppid()}/stat") as f:
+                    start = f.read().rsplit(")", 1)[1].split()[19]
+            except (OSError, IndexError):
+                start = "0"
+            key = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{start}"
             rendezvous_dir = os.path.join("/tmp", f"kkt_rdv_{key}")
         self._dir = rendezvous_dir
         self._timeout = timeout
