@@ -385,6 +385,7 @@ __global__ __launch_bounds__(512) void pc_row_program(const RowOp *__restrict__ 
 // buffer holding it (the alternate one) only after observing them -- which needs the
 // gather relation between workgroups to be symmetric (checked on the host).
 typedef KKT_GLOBAL unsigned long long *gu64_p;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // A phase descriptor (one RowOp, < 512 bytes) is fetched by ONE wave-wide vector load --
 // lane l holds bytes 8l..8l+7 -- a whole phase ahead, and its fields are moved to scalar
@@ -418,7 +419,8 @@ __device__ __forceinline__ gcd_p vref_ptr(long long off, int base) {
 template <int R, int W>
 __global__ __launch_bounds__(512) void pc_row_program_g(const RowOp *__restrict__ ops, int nphases,
                                                          unsigned long long *g0,
-                                                         unsigned long long *g1, unsigned *err) {
+                                                         unsigned long long *g1, unsigned gbytes,
+                                                         unsigned *err) {
     constexpr int C = 64 * R;
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -435,8 +437,14 @@ __global__ __launch_bounds__(512) void pc_row_program_g(const RowOp *__restrict_
     int c[W][R];
     double v[W][R];
     bool masked[R];
+    // what this wave published in the previous phase, by row within the slice: columns that
+    // are rows of the own slice are gathered from here instead of from memory
+    __shared__ double own_lds[8][C];
 #pragma unroll
-    for (int q = 0; q < R; ++q) masked[q] = false;
+    for (int q = 0; q < R; ++q) {
+        masked[q] = false;
+        own_lds[wave][lane + 64 * q] = 0.0;
+    }
 
 #define KKT_FETCH(dst, ptr)                                                      \
     do {                                                                         \
@@ -487,8 +495,9 @@ __global__ __launch_bounds__(512) void pc_row_program_g(const RowOp *__restrict_
         const bool active = s < op_nslices;
         const int nterms = active ? op_nterms : 0;
         KKT_STAGE(0);   // descriptor
-        const gu64_p xg = (gu64_p)((ph & 1) ? g0 : g1);   // written by phase ph-1
-        const gu64_p yg = (gu64_p)((ph & 1) ? g1 : g0);
+        // this phase's granule buffer as a raw buffer resource: one 16-byte sc1 store per row
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)((ph & 1) ? g1 : g0), 0, (int)gbytes, 0x00020000);
         const unsigned ep_in = (ph > 0 && op_nterms > 0) ? (unsigned)ph : 0u;
         const unsigned ep_out = (unsigned)(ph + 1);
         // program descriptors carry absolute pointers only (base 0) or null (base < 0)
@@ -562,29 +571,51 @@ __global__ __launch_bounds__(512) void pc_row_program_g(const RowOp *__restrict_
 #pragma unroll
                     for (int q = 0; q < R; ++q) xv[k][q] = x[c[k][q]];
             } else {
+                // Columns that are rows of this very slice were produced by this wave one phase
+                // ago: they come out of its LDS copy, bitwise the published values.  Only the
+                // other columns are polled in memory (two 8-byte agent-scope loads of
+                // {tag, lo} and {tag, hi}: 16-byte sc1 buffer LOADS were measured to return
+                // stale lines, scripts/microbench/xcd_handoff.hip); lanes that need nothing
+                // from memory all aim at one granule of their own slice, which already
+                // carries this phase's tag, so the poll stays branch-free and nearly free.
+                const gu64_p xg = (gu64_p)((ph & 1) ? g0 : g1);   // written by phase ph-1
+                unsigned long long ga[W][R], gb[W][R];
                 unsigned spins = 0;
                 bool ok;
-                do {
-                    ok = true;
+                while (true) {
 #pragma unroll
                     for (int k = 0; k < W; ++k)
 #pragma unroll
                         for (int q = 0; q < R; ++q) {
-                            const gu64_p g = xg + 2 * (size_t)c[k][q];
-                            const unsigned long long a =
-                                __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            const unsigned long long b =
-                                __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            ok &= (unsigned)(a >> 32) == ep_in && (unsigned)(b >> 32) == ep_in;
-                            xv[k][q] = __longlong_as_double(
-                                (long long)((a & 0xffffffffull) | (b << 32)));
+                            const bool own = (unsigned)(c[k][q] - s * C) < (unsigned)C;
+                            const gu64_p g = xg + 2 * (size_t)(own ? s * C : c[k][q]);
+                            ga[k][q] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            gb[k][q] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
-                    if (__all(ok) || dead) break;
-                } while (++spins < PROG_SPIN_LIMIT);
+                    ok = true;
+#pragma unroll
+                    for (int k = 0; k < W; ++k)
+#pragma unroll
+                        for (int q = 0; q < R; ++q)
+                            ok &= (unsigned)(ga[k][q] >> 32) == ep_in &&
+                                  (unsigned)(gb[k][q] >> 32) == ep_in;
+                    if (__all(ok) || dead || ++spins >= PROG_SPIN_LIMIT) break;
+                }
                 if (!__all(ok)) {
                     dead = true;
                     if (lane == 0) atomicOr(err, 2u);
                 }
+#pragma unroll
+                for (int k = 0; k < W; ++k)
+#pragma unroll
+                    for (int q = 0; q < R; ++q) {
+                        const int rel = c[k][q] - s * C;
+                        const bool own = (unsigned)rel < (unsigned)C;
+                        const double vo = own_lds[wave][rel & (C - 1)];
+                        const double vm = __longlong_as_double(
+                            (long long)((ga[k][q] & 0xffffffffull) | (gb[k][q] << 32)));
+                        xv[k][q] = own ? vo : vm;
+                    }
             }
         }
         KKT_STAGE(3);   // gather
@@ -642,12 +673,10 @@ __global__ __launch_bounds__(512) void pc_row_program_g(const RowOp *__restrict_
                 // the vector the next phase gathers: p_1 after a fused update, else y
                 const unsigned long long bits =
                     (unsigned long long)__double_as_longlong(y2 ? out2 : out);
-                const unsigned long long tag = (unsigned long long)ep_out << 32;
-                __hip_atomic_store(yg + 2 * (size_t)r, tag | (bits & 0xffffffffull),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(yg + 2 * (size_t)r + 1, tag | (bits >> 32), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+                const u32x4 g = {(unsigned)bits, ep_out, (unsigned)(bits >> 32), ep_out};
+                __builtin_amdgcn_raw_buffer_store_b128(g, ry, r * 16, 0, 16 /* sc1 */);
             }
+            own_lds[wave][lane + 64 * q] = y2 ? out2 : out;
         }
         // rotate the cache: what was produced one phase ago becomes "two phases ago"
 #ifdef KKT_STAMPS
@@ -685,11 +714,12 @@ __global__ __launch_bounds__(512) void pc_row_program_g(const RowOp *__restrict_
 #undef KKT_STAGE
 }
 
-typedef void (*progg_fn)(const RowOp *, int, unsigned long long *, unsigned long long *, unsigned *);
+typedef void (*progg_fn)(const RowOp *, int, unsigned long long *, unsigned long long *, unsigned,
+                         unsigned *);
 static progg_fn pick_program_g(int uniform_w) {
     switch (uniform_w) {
 #define KKT_W(n) case n: return pc_row_program_g<2, n>;
-        KKT_W(1) KKT_W(2) KKT_W(3) KKT_W(4) KKT_W(5) KKT_W(6) KKT_W(7) KKT_W(8)
+        KKT_W(1) KKT_W(2) KKT_W(3) KKT_W(4) KKT_W(5) KKT_W(6) KKT_W(7)
 #undef KKT_W
         default: return nullptr;   // wider rows: register pressure, use the counter form
     }
@@ -713,7 +743,7 @@ void launch_row_program_g(hipStream_t s, const RowOp *d_ops, int nphases, int nw
     (void)hipMemsetAsync(g0, 0, granule_words * sizeof(unsigned long long), s);
     (void)hipMemsetAsync(g1, 0, granule_words * sizeof(unsigned long long), s);
     hipLaunchKernelGGL(pick_program_g(uniform_w), dim3(nwg), dim3(64 * waves_per_wg), 0, s, d_ops,
-                       nphases, g0, g1, d_err);
+                       nphases, g0, g1, (unsigned)(granule_words * sizeof(unsigned long long)), d_err);
 }
 
 int prog_flag_words(int nwg) { return nwg * FLAG_STRIDE; }
