@@ -26,6 +26,18 @@ def _csr(A):
     return A
 
 
+def _axpby(a, A, b, B):
+    """``a A + b B``; matrices with identical index arrays are combined entry by entry, so
+    structural zeros survive and every block assembled over one connectivity keeps one
+    sparsity structure (what ``kkt_update_block_values`` relies on)."""
+    import numpy as np
+    if (A.shape == B.shape and A.nnz == B.nnz and np.array_equal(A.indptr, B.indptr)
+            and np.array_equal(A.indices, B.indices)):
+        return sp.csr_matrix((a * A.data + b * B.data, A.indices.copy(), A.indptr.copy()),
+                             shape=A.shape)
+    return _csr(a * A + b * B)
+
+
 def _own(A, share):
     return A if share else A.copy()
 
@@ -60,8 +72,8 @@ def instationary_blocks(M, K: Sequence, tau: float, beta: float, n_t: int,
         key = (a, id(K[i]), b, transpose)
         if share and key in cache:
             return cache[key]
-        Ki = K[i].T if transpose else K[i]
-        A = _csr(a * Ki + b * M)
+        Ki = _csr(K[i].T) if transpose else K[i]
+        A = _axpby(a, Ki, b, M)
         cache[key] = A
         return A
 

@@ -226,14 +226,55 @@ class TaylorHoodDiscretisation:
     coords_v: np.ndarray      # (n_v / 2, 2) node coordinates of one component
     coords_p: np.ndarray
     boundary_v: np.ndarray    # Dirichlet dofs of the vector space (both components)
+    elem: dict = None         # element data for re-assembly (P2-P1 triangles only)
 
     @property
     def n_v(self):
         return self.M_v.shape[0]
 
+    def convection_v(self, w: np.ndarray) -> sp.csr_matrix:
+        """``inner(dot(grad(trial), w), test) * dx`` on the velocity space for a P2 vector
+        field ``w`` (component-major), the Picard linearisation of the Navier-Stokes
+        convection term (``test/test_control.py:4194-4199``).  Same sparsity structure as
+        ``M_v`` / ``K_v`` entry by entry, so it can be re-uploaded with
+        ``kkt_update_block_values``."""
+        e = self._need_elem()
+        n2 = self.n_v // 2
+        V = e["V"]
+        wq = np.stack([e["phi"] @ w[:n2][V].T, e["phi"] @ w[n2:][V].T], axis=2)  # (nq, ne, 2)
+        adv = np.einsum("qed,eqbd->eqb", wq, e["gphi"])                # (w . grad phi_b)
+        Ne = np.einsum("eq,qa,eqb->eab", e["W"], e["phi"], adv)
+        N2 = _assemble_like(Ne, V, V, (n2, n2))
+        return _canonical_csr(sp.kron(sp.identity(2, format="csr"), N2))
+
+    def convection_p(self, w: np.ndarray) -> sp.csr_matrix:
+        """The same form on the pressure space (``construct_D_v(p_trial, p_test, ...)``,
+        ``control/control.py:3783-3785``): structure of ``M_p`` / ``K_p``."""
+        e = self._need_elem()
+        n2 = self.n_v // 2
+        V, Pn = e["V"], e["P"]
+        wq = np.stack([e["phi"] @ w[:n2][V].T, e["phi"] @ w[n2:][V].T], axis=2)
+        adv = np.einsum("qed,ecd->eqc", wq, e["glam"])                 # (w . grad lambda_c)
+        Ne = np.einsum("eq,qa,eqc->eac", e["W"], e["lam"], adv)
+        return _assemble_like(Ne, Pn, Pn, (self.n_p, self.n_p))
+
+    def _need_elem(self):
+        if self.elem is None:
+            raise NotImplementedError("re-assembly is implemented for rectangle_p2p1 only")
+        return self.elem
+
     @property
     def n_p(self):
         return self.M_p.shape[0]
+
+
+def _assemble_like(Ee, rows, cols, shape):
+    """Sum element matrices ``Ee[e, a, b]`` into CSR; entries are ordered by (row, column)
+    whatever their values, so every matrix assembled over the same connectivity has the
+    same ``indptr`` / ``indices``."""
+    r = np.repeat(rows, cols.shape[1], axis=1).ravel()
+    c = np.tile(cols, (1, rows.shape[1])).ravel()
+    return _canonical_csr(sp.coo_matrix((Ee.ravel(), (r, c)), shape=shape))
 
 
 def unit_square_q2q1(n: int) -> TaylorHoodDiscretisation:
@@ -294,12 +335,15 @@ def rectangle_p2p1(nx: int, ny: int, lx: float = 1.0, ly: float = 1.0) -> Taylor
     Pn = np.concatenate(tri_p, 0)           # (ne, 3)
     X = np.concatenate(tri_x, 0)            # (ne, 3, 2)
     ne = len(V)
-    # degree-4 quadrature on the reference triangle (6 points), barycentric
-    a1, a2 = 0.445948490915965, 0.091576213509771
-    w1, w2 = 0.223381589678011, 0.109951743655322
-    lam = np.array([[a1, a1, 1 - 2 * a1], [a1, 1 - 2 * a1, a1], [1 - 2 * a1, a1, a1],
+    # degree-5 quadrature on the reference triangle (Radon's 7 points), barycentric: exact
+    # for the mass matrix (degree 4) and for the convection form with a P2 field (degree 5)
+    s15 = np.sqrt(15.0)
+    a1, a2 = (6.0 - s15) / 21.0, (6.0 + s15) / 21.0
+    w1, w2 = (155.0 - s15) / 1200.0, (155.0 + s15) / 1200.0
+    lam = np.array([[1 / 3, 1 / 3, 1 / 3],
+                    [a1, a1, 1 - 2 * a1], [a1, 1 - 2 * a1, a1], [1 - 2 * a1, a1, a1],
                     [a2, a2, 1 - 2 * a2], [a2, 1 - 2 * a2, a2], [1 - 2 * a2, a2, a2]])
-    wq = 0.5 * np.array([w1, w1, w1, w2, w2, w2])
+    wq = 0.5 * np.array([9.0 / 40.0, w1, w1, w1, w2, w2, w2])
     # gradients of barycentric coordinates per element
     A = np.concatenate([np.ones((ne, 3, 1)), X], axis=2)
     Ainv = np.linalg.inv(A)
@@ -326,10 +370,7 @@ def rectangle_p2p1(nx: int, ny: int, lx: float = 1.0, ly: float = 1.0) -> Taylor
     Kpe = np.einsum("e,ecx,edx->ecd", 0.5 * detJ, glam, glam)
     n2, n1 = nvx * nvy, npx * (ny + 1)
 
-    def asm(Ee, rows, cols, shape):
-        r = np.repeat(rows, cols.shape[1], axis=1).ravel()
-        c = np.tile(cols, (1, rows.shape[1])).ravel()
-        return _canonical_csr(sp.coo_matrix((Ee.ravel(), (r, c)), shape=shape))
+    asm = _assemble_like
     M2 = asm(Me, V, V, (n2, n2))
     K2 = asm(Ke, V, V, (n2, n2))
     Bx = asm(Bxe, Pn, V, (n1, n2))
@@ -349,4 +390,5 @@ def rectangle_p2p1(nx: int, ny: int, lx: float = 1.0, ly: float = 1.0) -> Taylor
     return TaylorHoodDiscretisation(
         _canonical_csr(sp.kron(I2, M2)), _canonical_csr(sp.kron(I2, K2)),
         _canonical_csr(sp.hstack([Bx, By])), M_p, K_p, coords_v, coords_p,
-        np.concatenate([nb, nb + n2]).astype(np.int32))
+        np.concatenate([nb, nb + n2]).astype(np.int32),
+        elem=dict(V=V, P=Pn, W=W, phi=phi, gphi=gphi, lam=l, glam=glam))

@@ -228,6 +228,7 @@ class MultiBlockSystem:
         self._n1_loc = self._hi - self._lo if self._sharded else n_blocks_11
 
         share_ids = {}
+        self._structure = {}     # (quadrant, i, j) -> (nnz, hash of the index arrays)
         for q, blk in ((Q00, block_00), (Q01, block_01), (Q10, block_10), (Q11, block_11)):
             for (i, j), A in blk.items():                      # dict order = apply order
                 if A is None:
@@ -239,6 +240,7 @@ class MultiBlockSystem:
                 ncols = nx0 if q in (Q00, Q10) else nx1
                 # the same Python object given for several (i, j) shares device storage
                 sid = share_ids.setdefault(id(A), len(share_ids))
+                self._structure[(q, i, j)] = (len(data), hash(indices.tobytes()))
                 self._ck(self._lib.kkt_add_block(
                     self._h, q, i, j, nrows, ncols,
                     indptr.ctypes.data_as(_lib.c_i32p), indices.ctypes.data_as(_lib.c_i32p),
@@ -290,7 +292,10 @@ class MultiBlockSystem:
 
     def update_block_values(self, quadrant, i, j, A):
         """New values on a stored block's structure (Picard re-linearisation)."""
-        _, _, data = _as_csr(A)
+        _, indices, data = _as_csr(A)
+        if self._structure.get((quadrant, i, j)) != (len(data), hash(indices.tobytes())):
+            raise ValueError(f"block ({quadrant}; {i}, {j}): the new matrix does not have the "
+                             "stored sparsity structure")
         self._ck(self._lib.kkt_update_block_values(
             self._h, quadrant, i, j, data.ctypes.data_as(_lib.c_f64p)))
 

@@ -1,0 +1,225 @@
+"""Picard outer loop of instationary Navier-Stokes control (backward Euler).
+
+Host-side mirror of ``Control.Instationary.incompressible_non_linear_solve``
+(``control/control.py:4886-5232``): evaluate the non-linear residual at the current iterate
+(``:2442-2620`` for the velocity rows, ``:4976-5082`` for the pressure couplings), solve the
+linearised Stokes-control system for the update (``incompressible_linear_solve`` with the
+convection term frozen at ``v_old``, ``construct_D_v`` ``:1887-1896``), add it, repeat until
+``||r_k|| <= max(rtol ||r_0||, atol)`` or ``max_non_linear_iter``.
+
+The loop, the residual and the re-assembly of the convection blocks stay on the host, as in
+the reference; each outer iteration re-uploads only the values of the blocks that changed
+(``kkt_update_block_values``: same sparsity structure, no index traffic, preconditioner
+matrices refreshed on the device) and runs the linear solve on the GPU through
+``MultiBlockSystem.solve`` with a ``StokesPC``.
+
+Homogeneous Dirichlet velocity conditions (``bcs_v``, ``bcs_zeta``); the lifting of
+inhomogeneous ones belongs to the right-hand-side construction.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+import scipy.sparse as sp
+
+from .blocks import instationary_incompressible_blocks
+
+__all__ = ["NavierStokesControl", "GpuLinearSolver", "incompressible_non_linear_solve",
+           "non_linear_res_eval"]
+
+
+@dataclass
+class NavierStokesControl:
+    """What ``Control.Instationary`` holds for this driver: the Taylor-Hood discretisation,
+    ``forward_form = nu (grad u, grad v) + ((w . grad) u, v)`` (``test_control.py:4194-4199``),
+    nodal desired states ``v_d[i]`` and forces ``f[i]`` per time level, the initial
+    condition, ``beta`` and the time interval."""
+    disc: object
+    nu: float
+    beta: float
+    n_t: int
+    T: float
+    v_d: np.ndarray                      # (n_t, n_v)
+    f: np.ndarray                        # (n_t, n_v)
+    v_0: np.ndarray = None               # (n_v,), zero when omitted
+    t_0: float = 0.0
+
+    @property
+    def tau(self):
+        return (self.T - self.t_0) / (self.n_t - 1.0)
+
+    def D_v(self, w):
+        """``construct_D_v(v_trial, v_test, w, t)`` (Picard, ``control.py:1888-1889``)."""
+        return _same_structure_sum(self.disc.K_v, [(self.nu, self.disc.K_v),
+                                                   (1.0, self.disc.convection_v(w))])
+
+    def D_p(self, w):
+        """The same form on the pressure space (``control.py:3783-3785``)."""
+        return _same_structure_sum(self.disc.K_p, [(self.nu, self.disc.K_p),
+                                                   (1.0, self.disc.convection_p(w))])
+
+
+def _same_structure_sum(like, terms):
+    """``sum c_k A_k`` on the structure of ``like`` (explicit zeros kept, so the result can
+    replace a stored block's values entry by entry)."""
+    data = np.zeros_like(like.data)
+    for c, A in terms:
+        if A.nnz != like.nnz or not (np.array_equal(A.indptr, like.indptr)
+                                     and np.array_equal(A.indices, like.indices)):
+            raise ValueError("matrices assembled over different connectivities")
+        data += c * A.data
+    return sp.csr_matrix((data, like.indices.copy(), like.indptr.copy()), shape=like.shape)
+
+
+def non_linear_res_eval(pb: NavierStokesControl, D, v, zeta, p, mu):
+    """Residual rows of the BE Navier-Stokes control system at ``(v, zeta, p, mu)``
+    (``control.py:2456-2620`` + ``5003-5041``); ``D[i] = D_v(v[i])``.  Returns
+    ``(rhs_00, rhs_01, rhs_10, rhs_11)`` with Dirichlet rows zeroed (``bc.apply``)."""
+    th, n_t, tau, beta = pb.disc, pb.n_t, pb.tau, pb.beta
+    M, B = th.M_v, th.B
+    BT = sp.csr_matrix(B.T)
+    v_0 = np.zeros(th.n_v) if pb.v_0 is None else pb.v_0
+    r00 = np.zeros((n_t, th.n_v))
+    r01 = np.zeros((n_t, th.n_v))
+    for i in range(n_t):
+        Dz = tau * (D[i].T @ zeta[i]) + M @ zeta[i]
+        if i < n_t - 1:          # :2469-2497, :2552-2584
+            r00[i] = tau * (M @ pb.v_d[i]) - tau * (M @ v[i]) - Dz + M @ zeta[i + 1]
+        else:                    # :2541-2546
+            r00[i] = -Dz
+        Dv = tau * (D[i] @ v[i]) + M @ v[i]
+        if i == 0:               # :2499-2512: the initial-condition row
+            D0 = pb.D_v(v_0)
+            r01[0] = tau * (D0 @ v_0) + M @ v_0 - Dv
+        else:                    # :2518-2540, :2586-2615
+            r01[i] = (tau * (M @ pb.f[i]) + M @ v[i - 1] - Dv
+                      + (tau / beta) * (M @ zeta[i]))
+        r00[i] -= tau * (BT @ mu[i])        # :5004-5012
+        r01[i] -= tau * (BT @ p[i])         # :5017-5025
+    r00[:, th.boundary_v] = 0.0
+    r01[:, th.boundary_v] = 0.0
+    r10 = np.stack([-(B @ v[i]) for i in range(n_t)])       # :5030-5034
+    r11 = np.stack([-(B @ zeta[i]) for i in range(n_t)])    # :5036-5041
+    return r00, r01, r10, r11
+
+
+class GpuLinearSolver:
+    """The linearised solve of one Picard iteration on the GPU: builds the outer, inner
+    (velocity KKT) and commutator (pressure) systems once, afterwards only re-uploads the
+    values of the blocks that carry the re-linearised operator."""
+
+    def __init__(self, pb: NavierStokesControl, *, mass, schur, kp, mp, solver_parameters,
+                 device=0):
+        self.pb, self.device = pb, device
+        self.specs = dict(mass=mass, schur=schur, kp=kp, mp=mp)
+        self.solver_parameters = solver_parameters
+        self.outer = None
+        self.uploads = 0
+
+    def _blocks(self, D, Dp):
+        th, pb = self.pb.disc, self.pb
+        return instationary_incompressible_blocks(th.M_v, list(D), th.B, th.M_p, list(Dp),
+                                                  pb.tau, pb.beta, pb.n_t, False)
+
+    def _build(self, bl):
+        from .multiblock import (ChebSpec, ConstantNullspace, DirichletBCNullspace,
+                                 MultiBlockSystem, SchurPC, StokesPC)
+        th, pb, m = self.pb.disc, self.pb, self.pb.n_t
+        nsv = DirichletBCNullspace(th.boundary_v)
+        self.outer = MultiBlockSystem(
+            th.n_v, th.n_p, *bl["outer"], n_blocks_00=2 * m, n_blocks_11=2 * m,
+            nullspace_0=(nsv,) * (2 * m),
+            nullspace_1=tuple(ConstantNullspace() for _ in range(2 * m)), device=self.device)
+        self.inner = MultiBlockSystem(th.n_v, th.n_v, *bl["inner"], n_blocks_00=m,
+                                      n_blocks_11=m, nullspace_0=(nsv,) * m,
+                                      nullspace_1=(nsv,) * m, device=self.device)
+        self.comm = MultiBlockSystem(th.n_p, th.n_p, *bl["commutator"], n_blocks_00=m,
+                                     n_blocks_11=m, device=self.device)
+        s = self.specs
+        inner_pc = SchurPC(kind="BE", M=th.M_v, beta=pb.beta, bc_nodes=th.boundary_v,
+                           mass=ChebSpec(*s["mass"]), schur=ChebSpec(*s["schur"]), n_t=pb.n_t,
+                           tau=pb.tau)
+        self.pc = StokesPC(inner=self.inner, inner_pc=inner_pc, commutator=self.comm, B=th.B,
+                           K_p=th.K_p, M_p=th.M_p, kp=ChebSpec(*s["kp"]), mp=ChebSpec(*s["mp"]),
+                           n_p_blocks=m, b_scale=pb.tau, post_scale=1.0 / pb.tau**2)
+
+    def _update(self, bl):
+        """Blocks that depend on the linearisation point: ``tau D_i^T + M`` / ``tau D_i + M``
+        on the diagonal of ``block_01_int`` / ``block_10_int`` (``control.py:3806-3808``),
+        their copies inside the outer ``block_00``, and the pressure-space analogues."""
+        m = self.pb.n_t
+        i00, i01, i10, i11 = bl["inner"]
+        c00, c01, c10, c11 = bl["commutator"]
+        for i in range(m):
+            self.inner.update_block_values(1, i, i, i01[(i, i)])
+            self.inner.update_block_values(2, i, i, i10[(i, i)])
+            self.outer.update_block_values(0, i, m + i, i01[(i, i)])
+            self.outer.update_block_values(0, m + i, i, i10[(i, i)])
+            self.comm.update_block_values(1, i, i, c01[(i, i)])
+            self.comm.update_block_values(2, i, i, c10[(i, i)])
+            self.uploads += 6
+
+    def linear_solve(self, D, Dp, b_0, b_1):
+        bl = self._blocks(D, Dp)
+        if self.outer is None:
+            self._build(bl)
+        else:
+            self._update(bl)
+        u_0 = np.zeros_like(b_0)
+        u_1 = np.zeros_like(b_1)
+        ksp = self.outer.solve(u_0, u_1, b_0, b_1, solver_parameters=self.solver_parameters,
+                               pc_fn=self.pc)
+        return u_0, u_1, ksp.getIterationNumber()
+
+
+def incompressible_non_linear_solve(pb: NavierStokesControl, linear_solver, *,
+                                    max_non_linear_iter=10, relative_non_linear_tol=1.0e-5,
+                                    absolute_non_linear_tol=1.0e-8, v=None, zeta=None, p=None,
+                                    mu=None, print_error_non_linear=True):
+    """``control.py:4886-5232`` (BE).  ``linear_solver.linear_solve(D, Dp, b_0, b_1)`` returns
+    the update ``(u_0, u_1, iterations)`` of the linearised system whose forward operator at
+    time level ``i`` is ``D[i]`` (velocity space) / ``Dp[i]`` (pressure space).
+
+    Returns a dict with the converged fields, the non-linear residual norms (``norm_0``
+    first) and the linear iteration counts."""
+    th, n_t, tau = pb.disc, pb.n_t, pb.tau
+    z = lambda n: np.zeros((n_t, n))    # noqa: E731
+    v = z(th.n_v) if v is None else np.array(v, dtype=np.float64)
+    zeta = z(th.n_v) if zeta is None else np.array(zeta, dtype=np.float64)
+    p = z(th.n_p) if p is None else np.array(p, dtype=np.float64)
+    mu = z(th.n_p) if mu is None else np.array(mu, dtype=np.float64)
+    zeta[n_t - 1] = 0.0                                          # :4963
+
+    def evaluate():
+        D = [pb.D_v(v[i]) for i in range(n_t)]
+        r = non_linear_res_eval(pb, D, v, zeta, p, mu)
+        return D, r, float(np.sqrt(sum(np.vdot(x, x) for x in r)))
+
+    D, (r00, r01, r10, r11), norm_0 = evaluate()
+    norm_k = norm_0
+    norms, lin_its = [norm_0], []
+    if print_error_non_linear:
+        print(f"Initial non-linear residual: {norm_0:.16e}")
+    k = 0
+    while norm_k > relative_non_linear_tol * norm_0 and norm_k > absolute_non_linear_tol:
+        Dp = [pb.D_p(v[i]) for i in range(n_t)]
+        b_0 = np.concatenate([r00, r01])
+        b_1 = np.concatenate([tau * r10, tau * r11])             # :5102-5105
+        u_0, u_1, its = linear_solver.linear_solve(D, Dp, b_0, b_1)
+        lin_its.append(its)
+        v += u_0[:n_t]                                           # :5127-5147
+        zeta += u_0[n_t:]
+        zeta[:, th.boundary_v] = 0.0
+        mu += u_1[:n_t]          # pressure blocks: mu with the v rows, p with the zeta rows
+        p += u_1[n_t:]
+        D, (r00, r01, r10, r11), norm_k = evaluate()
+        norms.append(norm_k)
+        k += 1
+        if print_error_non_linear:
+            print(f"Non-linear solver: iteration {k:d}, non-linear residual norm {norm_k:.16e}")
+        if k + 1 > max_non_linear_iter:                          # :5186-5187
+            break
+    return dict(v=v, zeta=zeta, p=p, mu=mu, norms=norms, linear_iterations=lin_its,
+                converged=bool(norm_k <= relative_non_linear_tol * norm_0
+                               or norm_k <= absolute_non_linear_tol))

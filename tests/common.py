@@ -117,3 +117,51 @@ def stokes_gpu(p, specs=STOKES_SPECS):
                    M_p=th.M_p, kp=ChebSpec(*specs["kp"]), mp=ChebSpec(*specs["mp"]),
                    n_p_blocks=m, b_scale=p["tau"], post_scale=1.0 / p["tau"]**2, cn=CN)
     return outer, gpc
+
+
+# ------------------------------------------ Navier-Stokes control, Picard loop
+
+NS_SOLVER_PARAMETERS = {"linear_solver": "fgmres", "fgmres_restart": 10,
+                        "maximum_iterations": 100, "relative_tolerance": 1.0e-8,
+                        "absolute_tolerance": 0.0, "monitor_convergence": False}
+
+
+def navier_stokes_problem(n=4, n_t=4, nu=0.1, beta=1.0e-2, T=2.0):
+    """A small instance shaped like ``test/test_control.py:4160-4270`` (P2-P1 on
+    ``RectangleMesh(n, n, 2, 2)``, Picard convection, zero force and initial state) with a
+    smooth desired state that vanishes on the boundary."""
+    from control_amd.fem import rectangle_p2p1
+    from control_amd.picard import NavierStokesControl
+    th = rectangle_p2p1(n, n, 2.0, 2.0)
+    X, Y = th.coords_v[:, 0], th.coords_v[:, 1]
+    tau = T / (n_t - 1.0)
+    v_d = np.stack([np.cos(0.5 * np.pi * i * tau) * np.concatenate([
+        np.sin(0.5 * np.pi * X) ** 2 * np.sin(np.pi * Y),
+        -np.sin(np.pi * X) * np.sin(0.5 * np.pi * Y) ** 2]) for i in range(n_t)])
+    return NavierStokesControl(disc=th, nu=nu, beta=beta, n_t=n_t, T=T, v_d=v_d,
+                               f=np.zeros((n_t, th.n_v)))
+
+
+class OracleLinearSolver:
+    """The linearised solve of one Picard iteration in the CPU oracle (rebuilt every time)."""
+
+    def __init__(self, pb, specs=STOKES_SPECS, solver_parameters=NS_SOLVER_PARAMETERS):
+        self.pb, self.specs, self.sp = pb, specs, solver_parameters
+
+    def linear_solve(self, D, Dp, b_0, b_1):
+        from control_amd.blocks import instationary_incompressible_blocks
+        from oracle import kkt_oracle as ko
+        pb, th, m, s = self.pb, self.pb.disc, self.pb.n_t, self.specs
+        bl = instationary_incompressible_blocks(th.M_v, list(D), th.B, th.M_p, list(Dp),
+                                                pb.tau, pb.beta, pb.n_t, False)
+        osys = ko.OracleSystem(
+            th.n_v, th.n_p, *bl["outer"], n_blocks_00=2 * m, n_blocks_11=2 * m,
+            nullspace_0=tuple(ko.DirichletBCNullspace(th.boundary_v) for _ in range(2 * m)),
+            nullspace_1=tuple(ko.ConstantNullspace() for _ in range(2 * m)))
+        opc = ko.pc_instationary_incompressible(
+            th.M_v, bl["inner"], th.B, th.M_p, th.K_p, bl["commutator"], pb.n_t, pb.tau,
+            pb.beta, th.boundary_v, ko.ChebSpec(*s["mass"]), ko.ChebSpec(*s["schur"]),
+            ko.ChebSpec(*s["kp"]), ko.ChebSpec(*s["mp"]))
+        u_0, u_1 = np.zeros_like(b_0), np.zeros_like(b_1)
+        res = osys.solve(u_0, u_1, b_0, b_1, solver_parameters=self.sp, pc_fn=opc)
+        return u_0, u_1, res.its
