@@ -165,3 +165,74 @@ class OracleLinearSolver:
         u_0, u_1 = np.zeros_like(b_0), np.zeros_like(b_1)
         res = osys.solve(u_0, u_1, b_0, b_1, solver_parameters=self.sp, pc_fn=opc)
         return u_0, u_1, res.its
+
+
+# ------------------------------------------ Instationary.linear_solve driver
+
+class OracleBackend:
+    """``control_amd.control`` backend interface on the CPU oracle."""
+
+    def __init__(self, schur=(30, 0.02, 2.2)):
+        from oracle import kkt_oracle as ko
+        self._ko, self.schur = ko, schur
+        self.DirichletBCNullspace = ko.DirichletBCNullspace
+
+    def MultiBlockSystem(self, *a, **kw):
+        return self._ko.OracleSystem(*a, **kw)
+
+    def construct_pc(self, kind, M, block_01, block_10, n_t, tau, beta, nodes, lambda_v_bounds,
+                     epsilon):
+        ko = self._ko
+        mass, schur = ko.ChebSpec(20, *lambda_v_bounds), ko.ChebSpec(*self.schur)
+        if kind == "CN":
+            return ko.pc_instationary_CN(M, block_01, block_10, n_t, tau, beta, nodes, mass,
+                                         schur)
+        return ko.pc_instationary_BE(M, block_01, block_10, n_t, tau, beta, nodes, mass, schur,
+                                     epsilon=epsilon)
+
+
+def mms_heat_control(N, CN, n_t=10):
+    """``test/test_control.py:1658-1760`` (BE) / ``1983-2085`` (CN): heat control on
+    ``RectangleMesh(N, N, 2, 2)``, P1, beta = 1, exact solution linear in time,
+    ``v = 1`` on the boundary (inhomogeneous Dirichlet data)."""
+    from control_amd.control import Instationary
+    from control_amd.fem import rectangle_p1
+    disc = rectangle_p1(N, N, 2.0, 2.0)
+    beta, t_f = 1.0, 2.0
+
+    def c(X):
+        return np.cos(0.5 * np.pi * (X[:, 0] - 1.0)) * np.cos(0.5 * np.pi * (X[:, 1] - 1.0))
+
+    def ref_v(X, t):
+        return 1.0 + (t_f - t) * c(X)
+
+    def ref_zeta(X, t):
+        return (t_f - t) * c(X)
+
+    def desired_state(X, t):      # zeta_space - lapl(zeta) + v
+        return c(X) + 0.5 * np.pi**2 * (t_f - t) * c(X) + ref_v(X, t)
+
+    def force_f(X, t):            # - v_space - lapl(v) - zeta / beta
+        return -c(X) + 0.5 * np.pi**2 * (t_f - t) * c(X) - ref_zeta(X, t) / beta
+
+    ctl = Instationary(disc, desired_state=desired_state, force_f=force_f, beta=beta, CN=CN,
+                       n_t=n_t, initial_condition=lambda X: ref_v(X, 0.0),
+                       time_interval=(0.0, t_f), bcs_v=lambda Xb, t: np.ones(len(Xb)))
+    return ctl, disc, ref_v, ref_zeta
+
+
+MMS_SOLVER_PARAMETERS = {"linear_solver": "fgmres", "fgmres_restart": 10,
+                         "maximum_iterations": 200, "relative_tolerance": 1.0e-10,
+                         "absolute_tolerance": 1.0e-10, "monitor_convergence": False}
+
+
+def mms_errors(ctl, disc, ref_v, ref_zeta, n_t=10, t_f=2.0):
+    """sqrt(tau) * L2 error over the time levels, as ``test_control.py:1809-1817``."""
+    tau = t_f / (n_t - 1.0)
+    ev = ez = 0.0
+    for i in range(n_t):
+        dv = ctl._v[i] - ref_v(disc.coords, i * tau)
+        dz = ctl._zeta[i] - ref_zeta(disc.coords, i * tau)
+        ev += dv @ (disc.M @ dv)
+        ez += dz @ (disc.M @ dz)
+    return np.sqrt(tau * ev), np.sqrt(tau * ez)
