@@ -18,7 +18,7 @@ from __future__ import annotations
 import numpy as np
 import scipy.sparse as sp
 
-from .blocks import instationary_blocks
+from .blocks import instationary_blocks, instationary_incompressible_blocks
 
 __all__ = ["Instationary", "GpuBackend"]
 
@@ -29,7 +29,9 @@ class GpuBackend:
     def __init__(self, schur=(8, 0.07, 2.1), device=0):
         from . import multiblock as mb
         self._mb, self.schur, self.device = mb, schur, device
+        self.kp = schur                  # Chebyshev replacement of the AMG cycle on K_p
         self.DirichletBCNullspace = mb.DirichletBCNullspace
+        self.ConstantNullspace = mb.ConstantNullspace
 
     def MultiBlockSystem(self, *a, **kw):
         return self._mb.MultiBlockSystem(*a, device=self.device, **kw)
@@ -40,6 +42,24 @@ class GpuBackend:
         return mb.SchurPC(kind=kind, M=M, beta=beta, bc_nodes=nodes,
                           mass=mb.ChebSpec(20, *lambda_v_bounds),      # control.py:1967-1982
                           schur=mb.ChebSpec(*self.schur), n_t=n_t, tau=tau, epsilon=epsilon)
+
+
+    def construct_stokes_pc(self, th, blocks, n_t, tau, beta, CN, lambda_v_bounds,
+                            lambda_p_bounds, epsilon):
+        """``pc_fn`` of ``control.py:4318-4687`` as a ``StokesPC`` descriptor."""
+        mb, m = self._mb, blocks["m"]
+        nsv = mb.DirichletBCNullspace(th.boundary_v)
+        inner = self.MultiBlockSystem(th.n_v, th.n_v, *blocks["inner"], n_blocks_00=m,
+                                      n_blocks_11=m, nullspace_0=(nsv,) * m,
+                                      nullspace_1=(nsv,) * m, CN=CN)
+        comm = self.MultiBlockSystem(th.n_p, th.n_p, *blocks["commutator"], n_blocks_00=m,
+                                     n_blocks_11=m)
+        inner_pc = self.construct_pc("CN" if CN else "BE", th.M_v, None, None, n_t, tau, beta,
+                                     th.boundary_v, lambda_v_bounds, epsilon)
+        return mb.StokesPC(inner=inner, inner_pc=inner_pc, commutator=comm, B=th.B, K_p=th.K_p,
+                           M_p=th.M_p, kp=mb.ChebSpec(*self.kp),
+                           mp=mb.ChebSpec(20, *lambda_p_bounds), n_p_blocks=m, b_scale=tau,
+                           post_scale=1.0 / tau**2, cn=CN)
 
 
 def _apply_T_1(b):            # preconditioner.py:33-45
@@ -54,12 +74,30 @@ def _apply_T_2(b):            # preconditioner.py:48-60
     return out
 
 
+class _VelocitySpace:
+    """A Taylor-Hood discretisation seen as the space the velocity rows live on."""
+
+    def __init__(self, th):
+        nb = len(th.boundary_v) // 2
+        self.M, self.K, self.n_dofs = th.M_v, th.K_v, th.n_v
+        self.coords, self.boundary = th.coords_v, th.boundary_v
+        self.bc_coords = th.coords_v[th.boundary_v[:nb]]
+
+
 class Instationary:
-    """``Control.Instationary`` (``control/control.py:1713-1836``) for a scalar state."""
+    """``Control.Instationary`` (``control/control.py:1713-1836``).
+
+    ``disc`` is a ``SpatialDiscretisation`` (scalar state, ``linear_solve``) or a
+    ``TaylorHoodDiscretisation`` (velocity state, ``incompressible_linear_solve``: fields are
+    component-major vectors, ``bcs_v(Xb, t)`` returns the values of both components on the
+    boundary nodes ``Xb``, first component first)."""
 
     def __init__(self, disc, forward_operator=None, *, desired_state=None, force_f=None,
                  beta=1.0e-3, initial_condition=None, time_interval=(0.0, 1.0), CN=True,
                  n_t=20, bcs_v=None):
+        self._th = disc if hasattr(disc, "M_v") else None
+        if self._th is not None:
+            disc = _VelocitySpace(disc)
         self._disc = disc
         self._forward = forward_operator or (lambda v, t: disc.K)
         self._desired_state, self._force_f = desired_state, force_f
@@ -71,6 +109,9 @@ class Instationary:
         n = disc.n_dofs
         self._v = np.zeros((n_t, n))
         self._zeta = np.zeros((n_t, n))
+        if self._th is not None:
+            self._p = np.zeros((n_t, self._th.n_p))
+            self._mu = np.zeros((n_t, self._th.n_p))
 
     # -- control.py:1898-1941
     def _times(self):
@@ -95,8 +136,10 @@ class Instationary:
         t_0, _, tau = self._times()
         v = np.zeros(self._disc.n_dofs)
         if self._bcs_v is not None:
-            v[self._disc.boundary] = self._bcs_v(self._disc.coords[self._disc.boundary],
-                                                 t_0 + i * tau)
+            Xb = getattr(self._disc, "bc_coords", None)
+            if Xb is None:
+                Xb = self._disc.coords[self._disc.boundary]
+            v[self._disc.boundary] = self._bcs_v(Xb, t_0 + i * tau)
         return v
 
     def set_v(self, v):              # control.py:1838-1846
@@ -108,26 +151,15 @@ class Instationary:
         self._zeta = np.array(zeta, dtype=np.float64)
         self._zeta[:, self._disc.boundary] = 0.0
 
-    def linear_solve(self, *, P=None, solver_parameters=None, lambda_v_bounds=None,
-                     v_d=None, f=None, print_error=False, backend=None):
-        """``control.py:2800-3330``.  Returns the KSP-like object of the solve; the fields are
-        in ``self._v`` / ``self._zeta`` (all ``n_t`` levels, boundary values included)."""
-        backend = backend or GpuBackend()
-        disc, n_t, beta, CN = self._disc, self._n_t, self._beta, self._CN
+    def _velocity_rows(self, D, D_0, v_0, v_d, f, check_v_d, check_f):
+        """Rows of the adjoint (``b_0``) and state (``b_1``) equations before the CN
+        transforms: ``control.py:2991-3240`` (the same rows as ``3962-4245`` of the
+        incompressible driver)."""
+        disc, n_t, CN = self._disc, self._n_t, self._CN
         M, nodes = disc.M, disc.boundary
-        t_0, T_f, tau = self._times()
+        _, _, tau = self._times()
         inhom = self._bcs_v is not None
-        v_0 = (np.zeros(disc.n_dofs) if self._initial_condition is None
-               else np.asarray(self._initial_condition(disc.coords), dtype=np.float64))
-        check_f, check_v_d = f is None, v_d is None
-        if check_f:
-            f = self.construct_f()
-        if check_v_d:
-            v_d = self.construct_v_d()
-        v_old = self._v
-        D = [sp.csr_matrix(self._forward(v_old[i], t_0 + i * tau)) for i in range(n_t)]
-        b00, b01, b10, b11, m = instationary_blocks(M, D, tau, beta, n_t, CN)
-        D_0 = sp.csr_matrix(self._forward(v_0, t_0))
+        m = n_t - 1 if CN else n_t
 
         def bc_apply(b):             # homogenised bcs on a cofunction
             b[nodes] = 0.0
@@ -189,6 +221,31 @@ class Instationary:
             if check_f:                                              # :3228-3240
                 b_1[0] -= h * (D_0 @ v_0) - M @ v_0
                 bc_apply(b_1[0])
+        return b_0, b_1
+
+    def linear_solve(self, *, P=None, solver_parameters=None, lambda_v_bounds=None,
+                     v_d=None, f=None, print_error=False, backend=None):
+        """``control.py:2800-3330``.  Returns the KSP-like object of the solve; the fields are
+        in ``self._v`` / ``self._zeta`` (all ``n_t`` levels, boundary values included)."""
+        backend = backend or GpuBackend()
+        disc, n_t, beta, CN = self._disc, self._n_t, self._beta, self._CN
+        M, nodes = disc.M, disc.boundary
+        t_0, T_f, tau = self._times()
+        inhom = self._bcs_v is not None
+        v_0 = (np.zeros(disc.n_dofs) if self._initial_condition is None
+               else np.asarray(self._initial_condition(disc.coords), dtype=np.float64))
+        check_f, check_v_d = f is None, v_d is None
+        if check_f:
+            f = self.construct_f()
+        if check_v_d:
+            v_d = self.construct_v_d()
+        v_old = self._v
+        D = [sp.csr_matrix(self._forward(v_old[i], t_0 + i * tau)) for i in range(n_t)]
+        b00, b01, b10, b11, m = instationary_blocks(M, D, tau, beta, n_t, CN)
+        D_0 = sp.csr_matrix(self._forward(v_0, t_0))
+
+        b_0, b_1 = self._velocity_rows(D, D_0, v_0, v_d, f, check_v_d, check_f)
+        if CN:
             b_0 = _apply_T_1(b_0)                                    # :3242-3243
             b_1 = _apply_T_2(b_1)
 
@@ -220,4 +277,94 @@ class Instationary:
         else:
             self.set_v(v)
             self.set_zeta(zeta)
+        return ksp
+
+    def set_p(self, p):              # control.py:1858-1865
+        self._p = np.array(p, dtype=np.float64)
+
+    def set_mu(self, mu):
+        self._mu = np.array(mu, dtype=np.float64)
+
+    def incompressible_linear_solve(self, nullspace_p=None, *, forward_operator_p=None, P=None,
+                                    solver_parameters=None, lambda_v_bounds=None,
+                                    lambda_p_bounds=None, v_d=None, f=None, div_v=None,
+                                    div_zeta=None, print_error=False, backend=None):
+        """``control.py:3592-4760``: the Stokes-type control solve.  ``nullspace_p`` is the
+        nullspace class instance put on every pressure block (``ConstantNullspace()`` for
+        enclosed flow, ``test/test_control.py:3167``); ``forward_operator_p(v_i, t)`` is the
+        forward form on the pressure space (default ``K_p``, ``control.py:3783-3785``).
+        Fields afterwards: ``_v``, ``_zeta`` (``n_t`` levels), ``_p``, ``_mu`` (``m`` levels)."""
+        backend = backend or GpuBackend()
+        th = self._th
+        if th is None:
+            raise ValueError("Undefined space_p")                    # control.py:3604-3608
+        disc, n_t, beta, CN = self._disc, self._n_t, self._beta, self._CN
+        nodes = disc.boundary
+        t_0, T_f, tau = self._times()
+        inhom = self._bcs_v is not None
+        fwd_p = forward_operator_p or (lambda v, t: th.K_p)
+        v_0 = (np.zeros(disc.n_dofs) if self._initial_condition is None
+               else np.asarray(self._initial_condition(disc.coords), dtype=np.float64))
+        check_f, check_v_d = f is None, v_d is None
+        if check_f:
+            f = self.construct_f()
+        if check_v_d:
+            v_d = self.construct_v_d()
+        v_old = self._v
+        D = [sp.csr_matrix(self._forward(v_old[i], t_0 + i * tau)) for i in range(n_t)]
+        Dp = [sp.csr_matrix(fwd_p(v_old[i], t_0 + i * tau)) for i in range(n_t)]
+        D_0 = sp.csr_matrix(self._forward(v_0, t_0))
+        bl = instationary_incompressible_blocks(th.M_v, D, th.B, th.M_p, Dp, tau, beta, n_t, CN)
+        m = bl["m"]
+        b_0_0, b_0_1 = self._velocity_rows(D, D_0, v_0, v_d, f, check_v_d, check_f)
+        b_1_0 = np.zeros((m, th.n_p))
+        b_1_1 = np.zeros((m, th.n_p))
+        if div_v is None:                                            # :4088-4100, :4247-4258
+            if inhom:
+                for i in range(m):
+                    b_1_0[i] -= tau * (th.B @ self._bc_values(i + 1 if CN else i))
+        else:
+            b_1_0[:] = div_v
+        if div_zeta is not None:
+            b_1_1[:] = div_zeta
+        if CN:                                                       # :4266-4269
+            b_0_0, b_0_1 = _apply_T_1(b_0_0), _apply_T_2(b_0_1)
+            b_1_0, b_1_1 = _apply_T_2(b_1_0), _apply_T_1(b_1_1)
+        b_0 = np.concatenate([b_0_0, b_0_1])
+        b_1 = np.concatenate([b_1_0, b_1_1])
+
+        if solver_parameters is None:                                # :4291-4297
+            solver_parameters = {"linear_solver": "fgmres", "fgmres_restart": 10,
+                                 "maximum_iterations": 100, "relative_tolerance": 1.0e-6,
+                                 "absolute_tolerance": 0.0, "monitor_convergence": print_error}
+        if P is None:
+            pc_fn = backend.construct_stokes_pc(th, bl, n_t, tau, beta, CN,
+                                                lambda_v_bounds or (0.3924, 2.0598),
+                                                lambda_p_bounds or (0.5, 2.0), 1.0e-3)
+        else:
+            pc_fn = P
+        nsv = tuple(backend.DirichletBCNullspace(nodes) for _ in range(2 * m))
+        nsp = tuple((nullspace_p.__class__() if nullspace_p is not None
+                     else backend.ConstantNullspace()) for _ in range(2 * m))
+        kw = dict(sub_n_blocks_00_0=m, sub_n_blocks_11_0=m) if CN else {}
+        system = backend.MultiBlockSystem(th.n_v, th.n_p, *bl["outer"], n_blocks_00=2 * m,
+                                          n_blocks_11=2 * m, nullspace_0=nsv, nullspace_1=nsp,
+                                          CN=CN, **kw)                # :4274-4289
+        u_0 = np.zeros((2 * m, th.n_v))
+        u_1 = np.zeros((2 * m, th.n_p))
+        ksp = system.solve(u_0, u_1, b_0, b_1, solver_parameters=solver_parameters, pc_fn=pc_fn)
+        v = np.zeros((n_t, th.n_v))                                  # :4698-4726
+        zeta = np.zeros((n_t, th.n_v))
+        if CN:
+            if check_f and check_v_d:
+                v[0] = v_0
+            v[1:] = u_0[:m]
+            zeta[:m] = u_0[m:]
+        else:
+            v[:] = u_0[:m]
+            zeta[:] = u_0[m:]
+        self.set_v(v)
+        self.set_zeta(zeta)
+        self.set_mu(u_1[:m])
+        self.set_p(u_1[m:])
         return ksp

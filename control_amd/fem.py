@@ -161,20 +161,21 @@ def _p2_1d(n: int, length: float):
     return sp.csr_matrix(M), sp.csr_matrix(K), np.linspace(0.0, length, nn)
 
 
-def unit_square_q2(n: int) -> SpatialDiscretisation:
-    """Q2 on ``UnitSquareMesh(n, n, quadrilateral=True)`` (tensor-product form).
+def unit_square_q2(n: int, length: float = 1.0) -> SpatialDiscretisation:
+    """Q2 on ``UnitSquareMesh(n, n, quadrilateral=True)`` (tensor-product form); ``length``
+    scales the square (``RectangleMesh(n, n, length, length, quadrilateral=True)``).
 
     This is the space of the reference's known-answer tests
     (``test/test_control.py:1244-1247``).  Dof ``(i, j)`` of the ``(2n+1)^2`` grid
     has index ``j * (2n + 1) + i``.
     """
-    M1, K1, xs = _p2_1d(n, 1.0)
+    M1, K1, xs = _p2_1d(n, length)
     M = sp.kron(M1, M1)
     K = sp.kron(M1, K1) + sp.kron(K1, M1)
     XX, YY = np.meshgrid(xs, xs, indexing="xy")
     coords = np.stack([XX.ravel(), YY.ravel()], axis=1)
-    onb = ((coords[:, 0] == 0.0) | (coords[:, 0] == 1.0)
-           | (coords[:, 1] == 0.0) | (coords[:, 1] == 1.0))
+    onb = ((coords[:, 0] == 0.0) | (coords[:, 0] == xs[-1])
+           | (coords[:, 1] == 0.0) | (coords[:, 1] == xs[-1]))
     return SpatialDiscretisation(_canonical_csr(M), _canonical_csr(K), coords,
                                  np.flatnonzero(onb).astype(np.int32),
                                  f"Q2 {n}x{n}")
@@ -277,20 +278,20 @@ def _assemble_like(Ee, rows, cols, shape):
     return _canonical_csr(sp.coo_matrix((Ee.ravel(), (r, c)), shape=shape))
 
 
-def unit_square_q2q1(n: int) -> TaylorHoodDiscretisation:
-    sd = unit_square_q2(n)
+def unit_square_q2q1(n: int, length: float = 1.0) -> TaylorHoodDiscretisation:
+    sd = unit_square_q2(n, length)
     M2, K2 = sd.M, sd.K
     I2 = sp.identity(2, format="csr")
     M_v = _canonical_csr(sp.kron(I2, M2))
     K_v = _canonical_csr(sp.kron(I2, K2))
-    MX, DX, M1, K1 = _p1p2_1d(n, 1.0)
+    MX, DX, M1, K1 = _p1p2_1d(n, length)
     # dof (i, j) -> j * n_nodes_x + i  (y index major), as in unit_square_q2
     Bx = sp.kron(MX, DX)          # int q  d(v_x)/dx : (y: psi*phi) x (x: psi*phi')
     By = sp.kron(DX, MX)          # int q  d(v_y)/dy
     B = _canonical_csr(-sp.hstack([Bx, By]))
     M_p = _canonical_csr(sp.kron(M1, M1))
     K_p = _canonical_csr(sp.kron(M1, K1) + sp.kron(K1, M1))
-    xs = np.linspace(0.0, 1.0, n + 1)
+    xs = np.linspace(0.0, length, n + 1)
     XX, YY = np.meshgrid(xs, xs, indexing="xy")
     coords_p = np.stack([XX.ravel(), YY.ravel()], axis=1)
     nb = sd.boundary

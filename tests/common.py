@@ -236,3 +236,57 @@ def mms_errors(ctl, disc, ref_v, ref_zeta, n_t=10, t_f=2.0):
         ev += dv @ (disc.M @ dv)
         ez += dz @ (disc.M @ dz)
     return np.sqrt(tau * ev), np.sqrt(tau * ez)
+
+
+def _oracle_backend_stokes_pc(self, th, blocks, n_t, tau, beta, CN, lambda_v_bounds,
+                              lambda_p_bounds, epsilon):
+    ko = self._ko
+    return ko.pc_instationary_incompressible(
+        th.M_v, blocks["inner"], th.B, th.M_p, th.K_p, blocks["commutator"], n_t, tau, beta,
+        th.boundary_v, ko.ChebSpec(20, *lambda_v_bounds), ko.ChebSpec(*self.schur),
+        ko.ChebSpec(*self.schur), ko.ChebSpec(20, *lambda_p_bounds), CN=CN, epsilon=epsilon)
+
+
+OracleBackend.construct_stokes_pc = _oracle_backend_stokes_pc
+OracleBackend.ConstantNullspace = property(lambda self: self._ko.ConstantNullspace)
+
+
+def stokes_exact_sol_control(CN, n=8, n_t=20):
+    """``test/test_control.py:3045-3172`` (BE) / ``3175-3302`` (CN): instationary Stokes
+    control with an exact solution, Q2-Q1 on ``RectangleMesh(8, 8, 2, 2, quadrilateral=True)``,
+    beta = 1, time-dependent inhomogeneous Dirichlet data."""
+    from control_amd.control import Instationary
+    from control_amd.fem import unit_square_q2q1
+    th = unit_square_q2q1(n, 2.0)
+    T_f, beta = 1.0, 1.0
+
+    def true_v(X, t):
+        x, y = X[:, 0] - 1.0, X[:, 1] - 1.0
+        e = np.exp(T_f - t)
+        return np.concatenate([e * x * y**3, 0.25 * e * (x**4 - y**4)])
+
+    def desired_state(X, t):
+        x, y = X[:, 0] - 1.0, X[:, 1] - 1.0
+        e = np.exp(T_f - t)
+        h0 = 4.0 * beta * y * (2.0 * (3.0 * x * x - 1.0) * (y * y - 1.0) + 3.0 * (x * x - 1.0)**2)
+        h1 = -4.0 * beta * x * (3.0 * (y * y - 1.0)**2 + 2.0 * (x * x - 1.0) * (3.0 * y * y - 1.0))
+        d0 = e * (x * y**3 + 2.0 * beta * y * (((x * x - 1.0)**2) * (y * y - 7.0)
+                                               - 4.0 * (3.0 * x * x - 1.0) * (y * y - 1.0) + 2.0))
+        d1 = e * (0.25 * (x**4 - y**4) - 2.0 * beta * x * (((y * y - 1.0)**2) * (x * x - 7.0)
+                                                          - 4.0 * (x * x - 1.0) * (3.0 * y * y - 1.0)
+                                                          - 2.0))
+        return np.concatenate([d0 + h0, d1 + h1])
+
+    def force_f(X, t):
+        x, y = X[:, 0] - 1.0, X[:, 1] - 1.0
+        e = np.exp(T_f - t)
+        g0 = 2.0 * y * (x**2 - 1.0)**2 * (y**2 - 1.0)
+        g1 = -2.0 * x * (x**2 - 1.0) * (y**2 - 1.0)**2
+        f0 = e * (-x * y**3 - 2.0 * y * (x * x - 1.0)**2 * (y * y - 1.0))
+        f1 = e * (0.25 * (y**4 - x**4) + 2.0 * x * (x * x - 1.0) * (y * y - 1.0)**2)
+        return np.concatenate([f0 + g0, f1 + g1])
+
+    ctl = Instationary(th, desired_state=desired_state, force_f=force_f, beta=beta,
+                       initial_condition=lambda X: true_v(X, 0.0), time_interval=(0.0, T_f),
+                       CN=CN, n_t=n_t, bcs_v=lambda Xb, t: true_v(Xb, t))
+    return ctl, th, true_v

@@ -46,3 +46,45 @@ def test_mms_heat_control_on_the_gpu(CN):
     assert np.abs(ctl._zeta - ref._zeta).max() < 1e-7
     ev, ez = common.mms_errors(ctl, disc, ref_v, ref_zeta)
     assert ev < 2e-2 and ez < 2e-2
+
+
+@pytest.mark.parametrize("CN", [False, True])
+def test_instationary_stokes_control_with_exact_sol_oracle(CN):
+    """``test/test_control.py:3045-3172`` / ``3175-3302`` (the reference runs these without
+    asserting anything): the driver's right-hand sides and Dirichlet lifting reproduce the
+    exact velocity up to the discretisation error of the scheme."""
+    ctl, th, true_v = common.stokes_exact_sol_control(CN, n=4, n_t=8)
+    ksp = ctl.incompressible_linear_solve(lambda_v_bounds=(0.25, 1.5625),
+                                          lambda_p_bounds=(0.25, 2.25),
+                                          backend=common.OracleBackend())
+    assert ksp.reason > 0
+    tau = 1.0 / 7.0
+    err = 0.0
+    for i in range(8):
+        d = ctl._v[i] - true_v(th.coords_v, i * tau)
+        err += tau * (d @ (th.M_v @ d))
+    # measured on this coarse instance (4x4 Q2-Q1, 8 levels): 4.6e-3 (BE), 5.6e-3 (CN)
+    assert np.sqrt(err) < 1e-2
+    # boundary data of every level are on the state; the adjoint vanishes there
+    for i in range(8):
+        assert np.array_equal(ctl._v[i, th.boundary_v], true_v(th.coords_v, i * tau)[th.boundary_v])
+    assert np.all(ctl._zeta[:, th.boundary_v] == 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("CN", [False, True])
+def test_instationary_stokes_control_with_exact_sol_gpu(CN):
+    from control_amd.control import GpuBackend
+    sp_ = {"linear_solver": "fgmres", "fgmres_restart": 10, "maximum_iterations": 200,
+           "relative_tolerance": 1.0e-9, "absolute_tolerance": 0.0, "monitor_convergence": False}
+    ctl, th, true_v = common.stokes_exact_sol_control(CN, n=4, n_t=8)
+    ksp = ctl.incompressible_linear_solve(lambda_v_bounds=(0.25, 1.5625),
+                                          lambda_p_bounds=(0.25, 2.25), solver_parameters=sp_,
+                                          backend=GpuBackend(schur=(30, 0.02, 2.2)))
+    assert ksp.getConvergedReason() > 0
+    ref, *_ = common.stokes_exact_sol_control(CN, n=4, n_t=8)
+    ref.incompressible_linear_solve(lambda_v_bounds=(0.25, 1.5625),
+                                    lambda_p_bounds=(0.25, 2.25), solver_parameters=sp_,
+                                    backend=common.OracleBackend())
+    assert np.abs(ctl._v - ref._v).max() < 1e-6
+    assert np.abs(ctl._zeta - ref._zeta).max() < 1e-6
