@@ -44,11 +44,17 @@ SchurPC::SchurPC(System &S, const kkt_pc_desc &d) : S_(S), d_(d) {
     use_graph_ = !(e && e[0] == '1');
     e = std::getenv("KKT_PERSISTENT");
     use_programs_ = !(e && e[0] == '0');
+    // opt-in: measured 0-3 % on cfg 2 (both lanes slow down when they share the chip, and the
+    // smaller batches of a chunk are less efficient), DESIGN.md section 6
+    e = std::getenv("KKT_LANES");
+    use_lanes_ = e && e[0] == '1';
     build();
 }
 
 SchurPC::~SchurPC() {
     clear_program();
+    for (hipEvent_t e : events_) (void)hipEventDestroy(e);
+    if (side_) (void)hipStreamDestroy(side_);
     for (void *p : owned_)
         if (p) (void)hipFree(p);
 }
@@ -63,6 +69,25 @@ void SchurPC::clear_program() {
         if ((s.kind == PcStep::ROWS || s.kind == PcStep::PROG) && s.rows.d_ops)
             (void)hipFree(s.rows.d_ops);
     steps_.clear();
+    n_events_ = 0;
+    cur_lane_ = 0;
+}
+
+int SchurPC::emit_record(int lane) {
+    PcStep s;
+    s.kind = PcStep::EV_RECORD;
+    s.lane = lane;
+    s.ev = n_events_++;
+    steps_.push_back(s);
+    return s.ev;
+}
+
+void SchurPC::emit_wait(int lane, int ev) {
+    PcStep s;
+    s.kind = PcStep::EV_WAIT;
+    s.lane = lane;
+    s.ev = ev;
+    steps_.push_back(s);
 }
 
 void SchurPC::values_changed() {
@@ -339,6 +364,7 @@ void SchurPC::push_rows(std::vector<RowOp> &r) {
         s.rows.shared_matrix = s.rows.shared_matrix && op.nterms == 1 &&
                                op.t[0].vals == r[0].t[0].vals && op.col == r[0].col &&
                                op.rowmask == r[0].rowmask && op.t[0].x.base == 0;
+    s.lane = cur_lane_;
     steps_.push_back(s);
 }
 
@@ -421,6 +447,7 @@ void SchurPC::emit_time(double *y, const double *x, int kind, int n, const doubl
     s.nx = nx_;
     s.lo_halo = lo_halo;
     s.hi_halo = hi_halo;
+    s.lane = cur_lane_;
     steps_.push_back(s);
 }
 
@@ -516,44 +543,80 @@ void SchurPC::build_BE() {
     double *u0 = out_, *u1 = out_ + nl * nx_;
     auto blk = [&](double *base, int i) { return base + (int64_t)(i - lo) * nx_; };
     const int up = hi < n ? S_.rank + 1 : -1, dn = lo > 0 ? S_.rank - 1 : -1;
-    // (1,1)-block: u0_i = (1/tau) M~^-1 b0_i, last one also / epsilon   (2193-2206)
-    {
-        std::vector<Solve> sv;
-        for (int i = lo; i < hi; ++i)
-            sv.push_back(Solve{m_vals_, m_dinv_, blk(b0, i), blk(u0, i), 1.0 / tau,
-                               i == n - 1 ? 1.0 / eps : 1.0});
-        emit_solves(sv, d_.mass_its, d_.mass_emin, d_.mass_emax, P_, nx_);
+    // Unsharded handles split the level range into chunks: the mass solves and the
+    // right-hand-side products of chunk c run on the side lane while the forward sweep works
+    // through chunk c - 1 on the main lane.
+    const bool lanes = use_lanes_ && !S_.sharded && (hi - lo) >= 16;
+    int n_chunks = 1;
+    if (lanes) {
+        const char *e = std::getenv("KKT_LANE_CHUNKS");
+        n_chunks = std::max(2, std::min((hi - lo) / 4, e ? std::atoi(e) : 4));
     }
-    if (up >= 0 || dn >= 0) emit_comm(blk(u0, hi - 1), up, h_u0_, dn);
-    // b_i = block_10(i,i) u0_i + block_10(i,i-1) u0_{i-1} - b1_i   (2208-2237)
-    {
-        std::vector<Lin> ops;
-        for (int i = lo; i < hi; ++i) {
-            Lin l;
-            l.terms.push_back(Term{block_vals(KKT_Q10, i, i), blk(u0, i)});
-            if (i >= 1)
-                l.terms.push_back(Term{block_vals(KKT_Q10, i, i - 1),
-                                       i - 1 >= lo ? blk(u0, i - 1) : h_u0_});
-            l.y = blk(B_, i);
-            l.cz = -1.0;
-            l.z = blk(b1, i);
-            ops.push_back(l);
-        }
-        emit_lin(ops);
-    }
+    std::vector<int> cfirst(n_chunks + 1);
+    for (int c = 0; c <= n_chunks; ++c) cfirst[c] = lo + (int)((int64_t)(hi - lo) * c / n_chunks);
+    std::vector<int> chunk_done(n_chunks, -1);
     auto coef = [&](int i) { return i == 0 ? 0.0 : (i == n - 1 ? std::sqrt(eps) * shift : shift); };
+    auto side_chunk = [&](int c) {
+        const int c0 = cfirst[c], c1 = cfirst[c + 1];
+        cur_lane_ = lanes ? 1 : 0;
+        // (1,1)-block: u0_i = (1/tau) M~^-1 b0_i, last one also / epsilon   (2193-2206)
+        {
+            std::vector<Solve> sv;
+            for (int i = c0; i < c1; ++i)
+                sv.push_back(Solve{m_vals_, m_dinv_, blk(b0, i), blk(u0, i), 1.0 / tau,
+                                   i == n - 1 ? 1.0 / eps : 1.0});
+            double *const Pc[3] = {blk(P_[0], c0), blk(P_[1], c0), blk(P_[2], c0)};
+            emit_solves(sv, d_.mass_its, d_.mass_emin, d_.mass_emax, Pc, nx_);
+        }
+        if (c == n_chunks - 1 && (up >= 0 || dn >= 0)) emit_comm(blk(u0, hi - 1), up, h_u0_, dn);
+        // b_i = block_10(i,i) u0_i + block_10(i,i-1) u0_{i-1} - b1_i   (2208-2237)
+        {
+            std::vector<Lin> ops;
+            for (int i = c0; i < c1; ++i) {
+                Lin l;
+                l.terms.push_back(Term{block_vals(KKT_Q10, i, i), blk(u0, i)});
+                if (i >= 1)
+                    l.terms.push_back(Term{block_vals(KKT_Q10, i, i - 1),
+                                           i - 1 >= lo ? blk(u0, i - 1) : h_u0_});
+                l.y = blk(B_, i);
+                l.cz = -1.0;
+                l.z = blk(b1, i);
+                ops.push_back(l);
+            }
+            emit_lin(ops);
+        }
+        if (lanes) chunk_done[c] = emit_record(1);
+        cur_lane_ = 0;
+    };
     // forward sweep (2241-2327)
-    if (dn >= 0) emit_comm(nullptr, -1, h_u1_, dn);
-    for (int i = lo; i < hi; ++i) {
-        Mat F = schur_matrix(block_vals(KKT_Q10, i, i), coef(i));
-        const Solve sv{F.vals, F.dinv, blk(B_, i), blk(u1, i)};
-        if (i >= 1)
-            emit_update_and_solve(Lin{{Term{block_vals(KKT_Q10, i, i - 1),
-                                            i - 1 >= lo ? blk(u1, i - 1) : h_u1_}},
-                                      blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i), nullptr},
-                                  sv, d_.schur_its, d_.schur_emin, d_.schur_emax);
-        else
-            emit_solves({sv}, d_.schur_its, d_.schur_emin, d_.schur_emax, P_, nx_);
+    auto sweep_chunk = [&](int c) {
+        if (lanes) emit_wait(0, chunk_done[c]);
+        for (int i = cfirst[c]; i < cfirst[c + 1]; ++i) {
+            Mat F = schur_matrix(block_vals(KKT_Q10, i, i), coef(i));
+            const Solve sv{F.vals, F.dinv, blk(B_, i), blk(u1, i)};
+            if (i >= 1)
+                emit_update_and_solve(Lin{{Term{block_vals(KKT_Q10, i, i - 1),
+                                                i - 1 >= lo ? blk(u1, i - 1) : h_u1_}},
+                                          blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i), nullptr},
+                                      sv, d_.schur_its, d_.schur_emin, d_.schur_emax);
+            else
+                emit_solves({sv}, d_.schur_its, d_.schur_emin, d_.schur_emax, P_, nx_);
+        }
+    };
+    if (lanes) {
+        // host submission order interleaves the lanes: the sweep of chunk c (three calls) is
+        // queued before the ~20 launches of chunk c + 1, so neither stream waits for the host
+        const int e_start = emit_record(0);
+        emit_wait(1, e_start);
+        side_chunk(0);
+        for (int c = 0; c < n_chunks; ++c) {
+            sweep_chunk(c);
+            if (c + 1 < n_chunks) side_chunk(c + 1);
+        }
+    } else {
+        side_chunk(0);
+        if (dn >= 0) emit_comm(nullptr, -1, h_u1_, dn);
+        sweep_chunk(0);
     }
     if (up >= 0) emit_comm(blk(u1, hi - 1), up, nullptr, -1);
     // b_i = tau M u1_i (epsilon tau for the last)   (2330-2350)
@@ -680,15 +743,30 @@ void SchurPC::emit_comm(const double *send, int dst, double *recv, int src) {
     s.dst = dst;
     s.src = src;
     s.nx = nx_;
+    s.lane = cur_lane_;
     steps_.push_back(s);
 }
 
 void SchurPC::replay(size_t first, size_t last) {
-    hipStream_t st = S_.stream;
     Bases B{{nullptr, nullptr, nullptr, nullptr}};
+    if (n_events_ > 0 && !side_) {
+        HIPCHK(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+    }
+    while ((int)events_.size() < n_events_) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        events_.push_back(e);
+    }
     for (size_t k = first; k < last; ++k) {
         const PcStep &s = steps_[k];
+        hipStream_t st = s.lane == 0 ? S_.stream : side_;
         switch (s.kind) {
+            case PcStep::EV_RECORD:
+                HIPCHK(hipEventRecord(events_[s.ev], st));
+                break;
+            case PcStep::EV_WAIT:
+                HIPCHK(hipStreamWaitEvent(st, events_[s.ev], 0));
+                break;
             case PcStep::ROWS:
                 if (s.rows.shared_matrix &&
                     launch_rowops_shared(st, s.rows.d_ops, s.rows.nops, s.rows.max_slices,

@@ -11,7 +11,9 @@
 namespace kkt {
 
 struct PcStep {
-    enum Kind { ROWS, TIME, COPY, COMM, PROG } kind;
+    enum Kind { ROWS, TIME, COPY, COMM, PROG, EV_RECORD, EV_WAIT } kind;
+    int lane = 0;                   // 0: the system's stream; 1: the side stream
+    int ev = -1;                    // EV_RECORD / EV_WAIT: event index
     RowLaunch rows;                 // ROWS
     double *y = nullptr;            // TIME / COPY
     const double *x = nullptr;
@@ -83,6 +85,16 @@ class SchurPC : public PcBase {
     };
     std::vector<Segment> segments_;
     bool use_graph_ = true;
+    // Side lane: work that does not depend on the sweep in flight (the mass solves and the
+    // right-hand-side products of later time levels) runs on a second stream while the
+    // latency-bound sweep program occupies a quarter of the wave slots.
+    bool use_lanes_ = false;
+    hipStream_t side_ = nullptr;
+    std::vector<hipEvent_t> events_;
+    int cur_lane_ = 0;
+    int n_events_ = 0;
+    int emit_record(int lane);          // returns the event index
+    void emit_wait(int lane, int ev);
     // persistent row programs (kernels.hip, pc_row_program)
     bool use_programs_ = true;
     int prog_wpw_ = 0, prog_nwg_ = 0;
