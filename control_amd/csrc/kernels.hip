@@ -210,8 +210,18 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const Bases &bases,
         w = ((gci_p)op.slice_off)[s + 1] - off0;
     }
     const size_t base = (size_t)off0 * C + (size_t)lane * R;
-    const int r0 = s * C + lane;   // row of q is r0 + 64 * q
+    const int r0 = s * C + lane;   // position of q is r0 + 64 * q
     const int nrows = op.nrows;
+    // row-sorted structures (SELL-C-sigma): the row stored at a position comes from perm
+    int row[R];
+    {
+        const gci_p perm = (gci_p)op.perm;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int pos = r0 + 64 * q;
+            row[q] = perm ? perm[pos] : (pos < nrows ? pos : -1);
+        }
+    }
 
     // epilogue operands first: their latency overlaps the matrix stream
     double e0[R], e1[R], e2[R], e3[R];
@@ -232,8 +242,8 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const Bases &bases,
     }
 #pragma unroll
     for (int q = 0; q < R; ++q) {
-        const int r = r0 + 64 * q;
-        const bool in = r < nrows;
+        const int r = row[q];
+        const bool in = r >= 0;
         masked[q] = in && rowmask != nullptr && rowmask[r] != 0;
         e0[q] = (in && pa) ? ldv<COH>(pa + r) : 0.0;
         e1[q] = (in && pb) ? ldv<COH>(pb + r) : 0.0;
@@ -284,12 +294,12 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const Bases &bases,
     }
 #pragma unroll
     for (int q = 0; q < R; ++q)
-        if (r0 + 64 * q < nrows) stv<COH>(y + r0 + 64 * q, out[q]);
+        if (row[q] >= 0) stv<COH>(y + row[q], out[q]);
     if (lin && op.y2.base >= 0) {
         const gd_p y2 = (gd_p)resolve(op.y2, bases);
 #pragma unroll
         for (int q = 0; q < R; ++q)
-            if (r0 + 64 * q < nrows) stv<COH>(y2 + r0 + 64 * q, out2[q]);
+            if (row[q] >= 0) stv<COH>(y2 + row[q], out2[q]);
     }
 }
 
@@ -987,12 +997,15 @@ __global__ void extract_dinv_kernel(const int32_t *__restrict__ col,
                                     const int32_t *__restrict__ slice_off,
                                     const double *__restrict__ vals,
                                     const uint8_t *__restrict__ rowmask,
-                                    double *__restrict__ dinv, int nrows, int nslices) {
+                                    double *__restrict__ dinv, int nrows, int nslices,
+                                    const int32_t *__restrict__ perm) {
     constexpr int C = 64 * R;
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrows) return;
-    const int s = r / C;
-    const int rin = r - s * C;
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;   // position in the SELL storage
+    if (pos >= nslices * C) return;
+    const int r = perm ? perm[pos] : (pos < nrows ? pos : -1);
+    if (r < 0) return;
+    const int s = pos / C;
+    const int rin = pos - s * C;
     const int within = (rin % 64) * R + rin / 64;
     const int off0 = slice_off[s];
     const int w = slice_off[s + 1] - off0;
@@ -1009,14 +1022,14 @@ __global__ void extract_dinv_kernel(const int32_t *__restrict__ col,
 }
 void launch_extract_dinv(hipStream_t s, const int32_t *col, const int32_t *slice_off,
                          const double *vals, const uint8_t *rowmask, double *dinv,
-                         int nrows, int nslices, int R) {
-    dim3 grid((nrows + 255) / 256);
+                         int nrows, int nslices, int R, const int32_t *perm) {
+    dim3 grid((nslices * 64 * R + 255) / 256);
     if (R == 2)
         hipLaunchKernelGGL(extract_dinv_kernel<2>, grid, dim3(256), 0, s, col, slice_off,
-                           vals, rowmask, dinv, nrows, nslices);
+                           vals, rowmask, dinv, nrows, nslices, perm);
     else
         hipLaunchKernelGGL(extract_dinv_kernel<1>, grid, dim3(256), 0, s, col, slice_off,
-                           vals, rowmask, dinv, nrows, nslices);
+                           vals, rowmask, dinv, nrows, nslices, perm);
 }
 
 // ----------------------------------------------------------------------- vector kernels

@@ -33,6 +33,7 @@ enum EpiMode : int32_t { EPI_LIN = 0, EPI_CHEB = 1 };
 struct RowOp {
     const int32_t *col;        // SELL column indices of the shared pattern
     const int32_t *slice_off;  // nslices + 1 offsets, in slots
+    const int32_t *perm;       // row stored at each position (-1: none), null: position == row
     int32_t nrows, nslices, nterms, mode;
     int32_t uniform_w;         // >= 0: every slice has this width (slice_off unused)
     int32_t pad0_;
@@ -86,7 +87,7 @@ void launch_vals_axpy(hipStream_t s, double *out, const double *a, double c,
 // dinv[r] = rowmask[r] ? 1 : 1 / diag(A)[r]
 void launch_extract_dinv(hipStream_t s, const int32_t *col, const int32_t *slice_off,
                          const double *vals, const uint8_t *rowmask, double *dinv,
-                         int nrows, int nslices, int R);
+                         int nrows, int nslices, int R, const int32_t *perm = nullptr);
 
 // ---- vector kernels (all lengths in doubles)
 void launch_copy(hipStream_t s, double *y, const double *x, int64_t n);

@@ -140,16 +140,23 @@ void SchurPC::fuse_programs() {
         // every workgroup that gathers from its rows (write-after-read on rotating buffers)
         const int64_t rpw = (int64_t)wpw * 64 * P.R;
         std::vector<int32_t> lo(nwg), hi(nwg);
+        const int64_t npos = (int64_t)P.nslices * 64 * P.R;
         for (int j = 0; j < nwg; ++j) {
-            int64_t cmin = j * rpw, cmax = j * rpw;
-            const int64_t r1 = std::min<int64_t>(P.nrows, (j + 1) * rpw);
-            for (int64_t r = j * rpw; r < r1; ++r)
-                if (P.h_indptr[r + 1] > P.h_indptr[r]) {
-                    cmin = std::min<int64_t>(cmin, P.h_indices[P.h_indptr[r]]);
-                    cmax = std::max<int64_t>(cmax, P.h_indices[P.h_indptr[r + 1] - 1]);
+            // producers of the columns this workgroup gathers, as workgroup indices (positions
+            // of the rows in the SELL storage: row-sorted structures permute them)
+            int64_t wmin = j, wmax = j;
+            const int64_t p1 = std::min<int64_t>(npos, (j + 1) * rpw);
+            for (int64_t p = j * rpw; p < p1; ++p) {
+                const int64_t r = P.row_of(p);
+                if (r < 0) continue;
+                for (int32_t q = P.h_indptr[r]; q < P.h_indptr[r + 1]; ++q) {
+                    const int64_t w = P.pos_of(P.h_indices[q]) / rpw;
+                    wmin = std::min(wmin, w);
+                    wmax = std::max(wmax, w);
                 }
-            lo[j] = (int32_t)(cmin / rpw);
-            hi[j] = (int32_t)std::min<int64_t>(nwg - 1, cmax / rpw);
+            }
+            lo[j] = (int32_t)wmin;
+            hi[j] = (int32_t)std::min<int64_t>(nwg - 1, wmax);
         }
         std::vector<int32_t> slo = lo, shi = hi;
         for (int j = 0; j < nwg; ++j)
@@ -294,7 +301,7 @@ void SchurPC::build() {
     m_dinv_ = dev_alloc<double>(nx_);
     owned_.push_back(m_dinv_);
     launch_extract_dinv(st, P.d_col, P.d_slice_off, m_vals_, mask_, m_dinv_, (int)nx_, P.nslices,
-                        P.R);
+                        P.R, P.d_perm);
     {
         std::vector<int32_t> z(P.nslices + 1, 0);
         zero_off_ = dev_upload(z.data(), z.size());
@@ -333,7 +340,7 @@ SchurPC::Mat SchurPC::schur_matrix(const double *base_vals, double c) {
     launch_vals_axpy(st, m.vals, base_vals, c, m_vals_, P.npadded);
     if (mask_) launch_mask_columns(st, m.vals, P.d_col, mask_, P.npadded);
     launch_extract_dinv(st, P.d_col, P.d_slice_off, m.vals, mask_, m.dinv, (int)nx_, P.nslices,
-                        P.R);
+                        P.R, P.d_perm);
     mats_[key] = m;
     return m;
 }
@@ -375,6 +382,7 @@ void SchurPC::emit_lin(const std::vector<Lin> &ops) {
         if ((int)l.terms.size() > MAX_TERMS) fail(KKT_ERR_STATE, "too many terms");
         RowOp op{};
         op.col = P.d_col;
+        op.perm = P.d_perm;
         op.slice_off = l.terms.empty() ? zero_off_ : P.d_slice_off;
         op.uniform_w = l.terms.empty() ? 0 : P.uniform_w;
         op.nrows = (int32_t)nx_;
@@ -408,6 +416,7 @@ void SchurPC::emit_cheb(const std::vector<Cheb> &ops) {
     for (const Cheb &c : ops) {
         RowOp op{};
         op.col = P.d_col;
+        op.perm = P.d_perm;
         op.slice_off = c.vals ? P.d_slice_off : zero_off_;
         op.uniform_w = c.vals ? P.uniform_w : 0;
         op.nrows = (int32_t)nx_;

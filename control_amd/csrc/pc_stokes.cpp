@@ -13,6 +13,7 @@ static VRef vabs(const double *p) {
 static RowOp base_op(const Pattern &P) {
     RowOp op{};
     op.col = P.d_col;
+    op.perm = P.d_perm;
     op.slice_off = P.d_slice_off;
     op.uniform_w = P.uniform_w;
     op.nrows = (int32_t)P.nrows;
@@ -48,7 +49,7 @@ StokesPC::DevMat StokesPC::upload(int64_t nrows, int64_t ncols, const int32_t *i
         A.dinv = dev_alloc<double>(nrows);
         owned_.push_back(A.dinv);
         launch_extract_dinv(S_.stream, P.d_col, P.d_slice_off, A.vals, nullptr, A.dinv, (int)nrows,
-                            P.nslices, P.R);
+                            P.nslices, P.R, P.d_perm);
     }
     HIPCHK(hipStreamSynchronize(S_.stream));
     HIPCHK(hipFree(d_csr));

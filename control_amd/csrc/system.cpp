@@ -32,6 +32,7 @@ System::~System() {
     };
     for (auto &p : patterns) {
         F(p.d_col);
+        F(p.d_perm);
         F(p.d_slice_off);
         F(p.d_sell2csr);
     }
@@ -140,21 +141,28 @@ int System::find_or_add_pattern(int64_t nrows, int64_t ncols, const int32_t *ind
     P.h_indices.assign(indices, indices + nnz);
     const int C = 64 * P.R;
     P.nslices = (int)((nrows + C - 1) / C);
+    for (int64_t r = 0; r < nrows; ++r)
+        if (indptr[r + 1] < indptr[r]) fail(KKT_ERR_ARG, "indptr not monotone");
     std::vector<int32_t> off(P.nslices + 1, 0);
-    for (int s = 0; s < P.nslices; ++s) {
-        int w = 0;
-        const int64_t r1 = std::min<int64_t>(nrows, (int64_t)(s + 1) * C);
-        for (int64_t r = (int64_t)s * C; r < r1; ++r) {
-            if (indptr[r + 1] < indptr[r]) fail(KKT_ERR_ARG, "indptr not monotone");
-            w = std::max(w, indptr[r + 1] - indptr[r]);
+    // widths of the slices when position p holds row row_of(p)
+    auto measure = [&](const std::vector<int32_t> *row_of) {
+        P.max_width = 0;
+        P.uniform_w = -1;
+        for (int s = 0; s < P.nslices; ++s) {
+            int w = 0;
+            for (int64_t p = (int64_t)s * C; p < (int64_t)(s + 1) * C; ++p) {
+                const int64_t r = row_of ? (*row_of)[p] : (p < nrows ? p : -1);
+                if (r >= 0) w = std::max(w, indptr[r + 1] - indptr[r]);
+            }
+            P.max_width = std::max(P.max_width, w);
+            if (s == 0)
+                P.uniform_w = w;
+            else if (P.uniform_w != w)
+                P.uniform_w = -1;
+            off[s + 1] = off[s] + w;
         }
-        P.max_width = std::max(P.max_width, w);
-        if (s == 0)
-            P.uniform_w = w;
-        else if (P.uniform_w != w)
-            P.uniform_w = -1;
-        off[s + 1] = off[s] + w;
-    }
+    };
+    measure(nullptr);
     // Nearly uniform structures (structured meshes: only the slices that hold boundary
     // rows are narrower) are padded to one width so that the fixed-width kernels apply;
     // accepted when it costs at most 3 % more slots.
@@ -165,6 +173,41 @@ int System::find_or_add_pattern(int64_t nrows, int64_t ncols, const int32_t *ind
             P.uniform_w = P.max_width;
         }
     }
+    // Rows of very different lengths inside a slice (P2 / Q2 spaces, unstructured meshes) waste
+    // slots: sort the rows of every window of 8 slices by length (SELL-C-sigma) when that
+    // saves at least 10 % of the storage.  Vectors keep their order; kernels reach the row
+    // of a position through `perm`.
+    const char *sort_env = std::getenv("KKT_SELL_SORT");   // read per pattern: tests toggle it
+    const bool allow_sort = !(sort_env && sort_env[0] == '0');
+    if (allow_sort && nnz > 0) {
+        const int64_t npos = (int64_t)P.nslices * C, sigma = 8 * (int64_t)C;
+        std::vector<int32_t> cand(npos, -1);
+        for (int64_t w0 = 0; w0 < nrows; w0 += sigma) {
+            const int64_t w1 = std::min<int64_t>(nrows, w0 + sigma);
+            std::vector<int32_t> rows((size_t)(w1 - w0));
+            for (int64_t r = w0; r < w1; ++r) rows[r - w0] = (int32_t)r;
+            std::stable_sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) {
+                return indptr[a + 1] - indptr[a] > indptr[b + 1] - indptr[b];
+            });
+            for (int64_t r = w0; r < w1; ++r) cand[r] = rows[r - w0];
+        }
+        const int64_t before = off[P.nslices];
+        const int uni_before = P.uniform_w, maxw_before = P.max_width;
+        std::vector<int32_t> off_before = off;
+        measure(&cand);
+        if ((int64_t)off[P.nslices] * 10 <= before * 9) {
+            P.uniform_w = -1;
+            P.h_row_of = cand;
+            P.h_pos_of.assign(nrows, -1);
+            for (int64_t p = 0; p < npos; ++p)
+                if (cand[p] >= 0) P.h_pos_of[cand[p]] = (int32_t)p;
+            P.d_perm = dev_upload(cand.data(), cand.size());
+        } else {
+            off = off_before;
+            P.uniform_w = uni_before;
+            P.max_width = maxw_before;
+        }
+    }
     P.nslots = off[P.nslices];
     P.npadded = P.nslots * C;
     if (P.npadded >= (int64_t)1 << 31) fail(KKT_ERR_ARG, "block too large for int32 maps");
@@ -172,10 +215,10 @@ int System::find_or_add_pattern(int64_t nrows, int64_t ncols, const int32_t *ind
     for (int s = 0; s < P.nslices; ++s) {
         const int w = off[s + 1] - off[s];
         for (int within = 0; within < C; ++within) {
-            const int64_t r = (int64_t)s * C + (within % P.R) * 64 + within / P.R;   // lane-major
-            const int32_t self = (int32_t)std::min<int64_t>(std::min<int64_t>(r, nrows - 1),
-                                                            ncols - 1);
-            const int len = r < nrows ? indptr[r + 1] - indptr[r] : 0;
+            const int64_t pos = (int64_t)s * C + (within % P.R) * 64 + within / P.R;   // lane-major
+            const int64_t r = P.row_of(pos);
+            const int32_t self = (int32_t)std::min<int64_t>(r >= 0 ? r : nrows - 1, ncols - 1);
+            const int len = r >= 0 ? indptr[r + 1] - indptr[r] : 0;
             for (int k = 0; k < w; ++k) {
                 const int64_t p = ((int64_t)off[s] + k) * C + within;
                 if (k < len) {
@@ -195,7 +238,8 @@ int System::find_or_add_pattern(int64_t nrows, int64_t ncols, const int32_t *ind
     P.d_slice_off = dev_upload(off.data(), off.size());
     P.d_sell2csr = dev_upload(map.data(), map.size());
     patterns.push_back(std::move(P));
-    info.bytes_device_index += patterns.back().npadded * 4 + (patterns.back().nslices + 1) * 4;
+    info.bytes_device_index += patterns.back().npadded * 4 + (patterns.back().nslices + 1) * 4 +
+                               (patterns.back().d_perm ? (int64_t)patterns.back().nslices * C * 4 : 0);
     return (int)patterns.size() - 1;
 }
 
@@ -405,6 +449,7 @@ void System::finalize() {
                     const int pat = values[terms[t0]->va].pattern;
                     const Pattern &P = patterns[pat];
                     op.col = P.d_col;
+                    op.perm = P.d_perm;
                     op.slice_off = P.d_slice_off;
                     op.uniform_w = P.uniform_w;
                     op.nslices = P.nslices;

@@ -50,6 +50,12 @@ struct Pattern {
     int32_t *d_col = nullptr;
     int32_t *d_slice_off = nullptr;
     int32_t *d_sell2csr = nullptr;
+    // row-sorted storage (SELL-C-sigma): row held by each position / position of each row;
+    // empty and null when position == row
+    std::vector<int32_t> h_row_of, h_pos_of;
+    int32_t *d_perm = nullptr;
+    int64_t row_of(int64_t pos) const { return h_row_of.empty() ? (pos < nrows ? pos : -1) : h_row_of[pos]; }
+    int64_t pos_of(int64_t r) const { return h_pos_of.empty() ? r : h_pos_of[r]; }
 };
 
 struct ValueArray {
