@@ -899,6 +899,130 @@ __global__ __launch_bounds__(256) void pc_rows_shared(const RowOp *__restrict__ 
     }
 }
 
+// The same for structures without one fixed width (P2 / Q2, row-sorted storage): indices and
+// values are loaded in chunks of KC slots and serve NB time levels; every row keeps the fma
+// chain of the plain kernel (ascending k), so the results are bit-identical.
+template <int NB, int KC>
+__global__ __launch_bounds__(256) void pc_rows_shared_g(const RowOp *__restrict__ ops, int nops) {
+    constexpr int R = 2, C = 128;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + wave;
+    const int g0 = blockIdx.y * NB;
+    const RowOp &op0 = ops[g0];
+    if (s >= op0.nslices) return;
+    int off0, w;
+    if (op0.uniform_w >= 0) {
+        w = op0.uniform_w;
+        off0 = s * w;
+    } else {
+        off0 = ((gci_p)op0.slice_off)[s];
+        w = ((gci_p)op0.slice_off)[s + 1] - off0;
+    }
+    const size_t base = (size_t)off0 * C + (size_t)lane * R;
+    const int nrows = op0.nrows;
+    const Bases bases{{nullptr, nullptr, nullptr, nullptr}};
+    int row[R];
+    {
+        const gci_p perm = (gci_p)op0.perm;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int pos = s * C + lane + 64 * q;
+            row[q] = perm ? perm[pos] : (pos < nrows ? pos : -1);
+        }
+    }
+    const gcb_p rowmask = (gcb_p)op0.rowmask;
+    bool masked[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q)
+        masked[q] = row[q] >= 0 && rowmask != nullptr && rowmask[row[q]] != 0;
+    const int nb = nops - g0 < NB ? nops - g0 : NB;
+    gcd_p x[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) x[b] = resolve(ops[g0 + (b < nb ? b : 0)].t[0].x, bases);
+    double acc[NB][R];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[b][q] = 0.0;
+    const gci_p colp = (gci_p)op0.col + base;
+    const gcd_p vp = (gcd_p)op0.t[0].vals + base;
+    for (int k0 = 0; k0 < w; k0 += KC) {
+        int c[KC][R];
+        double v[KC][R];
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+            if (k0 + k < w) {
+                load_cols<R>(colp + (size_t)(k0 + k) * C, c[k]);
+                load_vals<R, false>(vp + (size_t)(k0 + k) * C, v[k]);
+            }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            double xv[KC][R];
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+                if (k0 + k < w) {
+#pragma unroll
+                    for (int q = 0; q < R; ++q) xv[k][q] = x[b][c[k][q]];
+                }
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+                if (k0 + k < w) {
+#pragma unroll
+                    for (int q = 0; q < R; ++q)
+                        acc[b][q] = __builtin_fma(v[k][q], xv[k][q], acc[b][q]);
+                }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (b >= nb) break;
+        const RowOp &op = ops[g0 + b];
+        const bool lin = op.mode == EPI_LIN;
+        gcd_p pa, pb, pc, pd;
+        if (lin) {
+            pa = resolve(op.yin, bases);
+            pb = resolve(op.z, bases);
+            pc = resolve(op.mx, bases);
+            pd = op.y2.base >= 0 ? (gcd_p)op.dinv : nullptr;
+        } else {
+            pa = resolve(op.pkm1, bases);
+            pb = resolve(op.pk, bases);
+            pc = resolve(op.b, bases);
+            pd = (gcd_p)op.dinv;
+        }
+        const gd_p y = (gd_p)resolve(op.y, bases);
+        const gd_p y2 = lin && op.y2.base >= 0 ? (gd_p)resolve(op.y2, bases) : nullptr;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int r = row[q];
+            if (r < 0) continue;
+            const double e0 = pa ? pa[r] : 0.0, e1 = pb ? pb[r] : 0.0;
+            const double e2 = pc ? pc[r] : 0.0, e3 = pd ? pd[r] : 0.0;
+            double out, out2 = 0.0;
+            if (lin) {
+                if (masked[q]) {
+                    out = pc ? op.malpha * e2 : 0.0;
+                } else {
+                    out = op.ca * acc[b][q];
+                    if (pa) out += op.cy * e0;
+                    if (pb) out += op.cz * e1;
+                }
+                out2 = op.c3 * (e3 * out);
+            } else if (masked[q]) {
+                out = 0.0;
+            } else {
+                double t = pa ? op.c1 * e0 : 0.0;
+                if (pb) t += op.c2 * e1;
+                t += op.c3 * (e3 * (e2 - acc[b][q]));
+                out = op.post2 * (op.post1 * t);
+            }
+            y[r] = out;
+            if (y2) y2[r] = out2;
+        }
+    }
+}
+
 bool launch_rowops_shared(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, int R,
                           int uniform_w) {
     constexpr int NB = 4;
@@ -908,7 +1032,9 @@ bool launch_rowops_shared(hipStream_t s, const RowOp *d_ops, int nops, int max_s
 #define KKT_W(n) case n: hipLaunchKernelGGL((pc_rows_shared<n, NB>), grid, block, 0, s, d_ops, nops); return true;
         KKT_W(1) KKT_W(2) KKT_W(3) KKT_W(4) KKT_W(5) KKT_W(6) KKT_W(7) KKT_W(8)
 #undef KKT_W
-        default: return false;
+        default:
+            hipLaunchKernelGGL((pc_rows_shared_g<NB, 4>), grid, block, 0, s, d_ops, nops);
+            return true;
     }
 }
 
