@@ -18,9 +18,10 @@ from __future__ import annotations
 import numpy as np
 import scipy.sparse as sp
 
-from .blocks import instationary_blocks, instationary_incompressible_blocks
+from .blocks import (instationary_blocks, instationary_incompressible_blocks,
+                     stationary_blocks)
 
-__all__ = ["Instationary", "GpuBackend"]
+__all__ = ["Instationary", "Stationary", "GpuBackend"]
 
 
 class GpuBackend:
@@ -368,3 +369,135 @@ class Instationary:
         self.set_mu(u_1[:m])
         self.set_p(u_1[m:])
         return ksp
+
+
+class Stationary:
+    """``Control.Stationary`` (``control/control.py:100-800``) for a scalar state:
+    ``linear_solve`` (``:487-604``) and the Picard / Gauss-Newton loop ``non_linear_solve``
+    (``:640-760``).
+
+    ``forward_operator(v_old) -> csr`` is ``forward_form(trial, test, v_old)`` assembled;
+    ``forward_jacobian(v_old) -> csr`` its Gateaux derivative in the direction of ``trial``
+    (``ufl.derivative``, ``control.py:314-318``), used after ``set_Gauss_Newton()``."""
+
+    def __init__(self, disc, forward_operator=None, *, desired_state=None, force_f=None,
+                 beta=1.0e-3, bcs_v=None, forward_jacobian=None):
+        self._disc = disc
+        self._forward = forward_operator or (lambda v: disc.K)
+        self._jacobian = forward_jacobian
+        self._Gauss_Newton = False
+        self._desired_state, self._force_f = desired_state, force_f
+        self._beta = float(beta)
+        self._bcs_v = bcs_v
+        self._v = np.zeros(disc.n_dofs)
+        self._zeta = np.zeros(disc.n_dofs)
+
+    def set_Gauss_Newton(self):
+        if self._jacobian is None:
+            raise ValueError("Gauss-Newton needs forward_jacobian")
+        self._Gauss_Newton = True
+
+    def set_Picard(self):
+        self._Gauss_Newton = False
+
+    def construct_D_v(self, v_old):          # control.py:310-320
+        return sp.csr_matrix(self._jacobian(v_old) if self._Gauss_Newton
+                             else self._forward(v_old))
+
+    def _v_inhom(self):
+        v = np.zeros(self._disc.n_dofs)
+        if self._bcs_v is not None:
+            v[self._disc.boundary] = self._bcs_v(self._disc.coords[self._disc.boundary])
+        return v
+
+    def set_v(self, v):                      # control.py:264-272
+        self._v = np.array(v, dtype=np.float64)
+        self._v[self._disc.boundary] = self._v_inhom()[self._disc.boundary]
+
+    def set_zeta(self, zeta):                # control.py:274-283
+        self._zeta = np.array(zeta, dtype=np.float64)
+        self._zeta[self._disc.boundary] = 0.0
+
+    def _data(self):
+        M, X = self._disc.M, self._disc.coords
+        f = (M @ self._force_f(X)) if self._force_f is not None else np.zeros(len(X))
+        return M @ self._desired_state(X), f
+
+    def linear_solve(self, *, P=None, solver_parameters=None, lambda_v_bounds=None, v_d=None,
+                     f=None, print_error=False, backend=None):
+        backend = backend or GpuBackend()
+        disc, beta = self._disc, self._beta
+        M, nodes = disc.M, disc.boundary
+        inhom = self._bcs_v is not None
+        D_v = self.construct_D_v(self._v)
+        v_inhom = self._v_inhom()
+        if f is None or v_d is None:
+            v_d_data, f_data = self._data()
+        if f is None:                        # construct_f, control.py:322-332
+            f = f_data - (D_v @ v_inhom if inhom else 0.0)
+            f[nodes] = 0.0 if inhom else f[nodes]
+        if v_d is None:                      # construct_v_d, control.py:334-346
+            v_d = v_d_data - (M @ v_inhom if inhom else 0.0)
+            v_d[nodes] = 0.0 if inhom else v_d[nodes]
+        b00, b01, b10, b11 = stationary_blocks(M, D_v, beta)
+        if P is None:
+            pc_fn = backend.construct_pc("stationary", M, b01, b10, 1, 0.0, beta, nodes,
+                                         lambda_v_bounds or (0.5, 2.0), 0.0)
+        else:
+            pc_fn = P
+        if solver_parameters is None:        # control.py:556-562
+            solver_parameters = {"linear_solver": "gmres", "gmres_restart": 10,
+                                 "maximum_iterations": 50, "relative_tolerance": 1.0e-6,
+                                 "absolute_tolerance": 0.0, "monitor_convergence": print_error}
+        ns = (backend.DirichletBCNullspace(nodes),)
+        system = backend.MultiBlockSystem(disc.n_dofs, disc.n_dofs, b00, b01, b10, b11,
+                                          nullspace_0=ns, nullspace_1=ns)
+        v = np.zeros((1, disc.n_dofs))
+        zeta = np.zeros((1, disc.n_dofs))
+        ksp = system.solve(v, zeta, np.atleast_2d(v_d), np.atleast_2d(f),
+                           solver_parameters=solver_parameters, pc_fn=pc_fn)
+        self.set_v(v[0] + (v_inhom if inhom else 0.0))          # control.py:572-577
+        self.set_zeta(zeta[0])
+        return ksp
+
+    def non_linear_res_eval(self, v_d, f, v_old, zeta_old, D_v):   # control.py:452-486
+        M, nodes, beta = self._disc.M, self._disc.boundary, self._beta
+        rhs_0 = v_d - M @ v_old - D_v.T @ zeta_old
+        rhs_1 = f - D_v @ v_old + (1.0 / beta) * (M @ zeta_old)
+        rhs_0[nodes] = 0.0
+        rhs_1[nodes] = 0.0
+        return rhs_0, rhs_1
+
+    def non_linear_solve(self, *, P=None, solver_parameters=None, lambda_v_bounds=None,
+                         max_non_linear_iter=10, relative_non_linear_tol=1.0e-5,
+                         absolute_non_linear_tol=1.0e-8, print_error_non_linear=False,
+                         backend=None):
+        """``control.py:640-760``; returns the residual norms (initial one first)."""
+        v_old, zeta_old = self._v.copy(), self._zeta.copy()
+        v_d, f = self._data()
+        D_v = self.construct_D_v(v_old)
+        rhs_0, rhs_1 = self.non_linear_res_eval(v_d, f, v_old, zeta_old, D_v)
+        norm_0 = float(np.sqrt(rhs_0 @ rhs_0 + rhs_1 @ rhs_1))
+        norm_k, k, norms = norm_0, 0, [norm_0]
+        while norm_k > relative_non_linear_tol * norm_0 and norm_k > absolute_non_linear_tol:
+            self.linear_solve(P=P, solver_parameters=solver_parameters,
+                              lambda_v_bounds=lambda_v_bounds, v_d=rhs_0, f=rhs_1,
+                              backend=backend)
+            v_old = v_old + self._v
+            if self._bcs_v is not None:
+                v_old[self._disc.boundary] = self._v_inhom()[self._disc.boundary]
+            self.set_v(v_old)
+            zeta_old = zeta_old + self._zeta
+            self.set_zeta(zeta_old)
+            zeta_old = self._zeta.copy()
+            D_v = self.construct_D_v(v_old)
+            rhs_0, rhs_1 = self.non_linear_res_eval(v_d, f, v_old, zeta_old, D_v)
+            norm_k = float(np.sqrt(rhs_0 @ rhs_0 + rhs_1 @ rhs_1))
+            norms.append(norm_k)
+            k += 1
+            if print_error_non_linear:
+                print(f"Non-linear solver: iteration {k:d}, non-linear residual norm "
+                      f"{norm_k:.16e}")
+            if k + 1 > max_non_linear_iter:
+                break
+        return norms

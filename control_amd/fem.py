@@ -37,10 +37,32 @@ class SpatialDiscretisation:
     coords: np.ndarray        # (N_x, dim) dof coordinates
     boundary: np.ndarray      # int32 sorted dof indices on the whole boundary
     name: str = ""
+    cells: np.ndarray = None  # (n_cells, 3) vertex indices (P1 triangles only)
 
     @property
     def n_dofs(self) -> int:
         return self.M.shape[0]
+
+    def weighted_mass(self, w) -> sp.csr_matrix:
+        """``w(X) * inner(trial, test) * dx`` for a coefficient given by its values at
+        quadrature points: ``w(lam)`` receives the barycentric coordinates ``(nq, 3)`` of
+        Radon's 7-point rule and the cell connectivity and returns ``(n_cells, nq)`` values.
+        P1 triangles; same structure as ``M``."""
+        if self.cells is None:
+            raise NotImplementedError("weighted_mass needs a P1 triangle discretisation")
+        s15 = np.sqrt(15.0)
+        a1, a2 = (6.0 - s15) / 21.0, (6.0 + s15) / 21.0
+        w1, w2 = (155.0 - s15) / 1200.0, (155.0 + s15) / 1200.0
+        lam = np.array([[1 / 3, 1 / 3, 1 / 3],
+                        [a1, a1, 1 - 2 * a1], [a1, 1 - 2 * a1, a1], [1 - 2 * a1, a1, a1],
+                        [a2, a2, 1 - 2 * a2], [a2, 1 - 2 * a2, a2], [1 - 2 * a2, a2, a2]])
+        wq = np.array([9.0 / 40.0, w1, w1, w1, w2, w2, w2])
+        X = self.coords[self.cells]
+        d1, d2 = X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]
+        area = 0.5 * np.abs(d1[:, 0] * d2[:, 1] - d1[:, 1] * d2[:, 0])
+        W = np.asarray(w(lam, self.cells)) * wq[None, :] * area[:, None]
+        Me = np.einsum("cq,qa,qb->cab", W, lam, lam)
+        return _assemble_like(Me, self.cells, self.cells, self.M.shape)
 
 
 def _canonical_csr(A: sp.spmatrix) -> sp.csr_matrix:
@@ -103,7 +125,7 @@ def rectangle_p1(nx: int, ny: int, lx: float = 1.0, ly: float = 1.0,
            | (coords[:, 1] == ys[0]) | (coords[:, 1] == ys[-1]))
     return SpatialDiscretisation(M, K, coords,
                                  np.flatnonzero(onb).astype(np.int32),
-                                 f"P1 {nx}x{ny}")
+                                 f"P1 {nx}x{ny}", cells)
 
 
 def unit_square_p1(n: int, diagonal: str = "right") -> SpatialDiscretisation:

@@ -184,6 +184,9 @@ class OracleBackend:
                      epsilon):
         ko = self._ko
         mass, schur = ko.ChebSpec(20, *lambda_v_bounds), ko.ChebSpec(*self.schur)
+        if kind == "stationary":
+            return ko.pc_stationary(M, block_10[(0, 0)], block_01[(0, 0)], beta, nodes, mass,
+                                    schur)
         if kind == "CN":
             return ko.pc_instationary_CN(M, block_01, block_10, n_t, tau, beta, nodes, mass,
                                          schur)

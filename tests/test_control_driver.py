@@ -88,3 +88,90 @@ def test_instationary_stokes_control_with_exact_sol_gpu(CN):
                                     backend=common.OracleBackend())
     assert np.abs(ctl._v - ref._v).max() < 1e-6
     assert np.abs(ctl._zeta - ref._zeta).max() < 1e-6
+
+
+# ------------------------------------------------------------------ Control.Stationary
+
+KAT_SP = {"linear_solver": "fgmres", "fgmres_restart": 10, "maximum_iterations": 500,
+          "relative_tolerance": 1.0e-14, "absolute_tolerance": 1.0e-14,
+          "monitor_convergence": False}
+
+
+def _stationary_reference_problem(nonlinear=False):
+    """``test/test_control.py:554-600`` (linear) / ``710-765`` (Picard): P1 on
+    ``UnitSquareMesh(8, 8)``, ``-lapl(v) + alpha(v) v = m``, beta = 1, desired state
+    ``sin(pi x) sin(pi y) exp(x + y)``, homogeneous Dirichlet conditions."""
+    from control_amd.control import Stationary
+    from control_amd.fem import unit_square_p1
+    disc = unit_square_p1(8)
+
+    def v_d(X):
+        return np.sin(np.pi * X[:, 0]) * np.sin(np.pi * X[:, 1]) * np.exp(X[:, 0] + X[:, 1])
+    if nonlinear:
+        def forward(v_old):     # grad-grad + (2 + 0.5 v_old^2) mass, test_control.py:715-719
+            return disc.K + disc.weighted_mass(
+                lambda lam, cells: 2.0 + 0.5 * (v_old[cells] @ lam.T) ** 2)
+    else:
+        def forward(v_old):     # test_control.py:559-563
+            return disc.K + 2.0 * disc.M
+    return Stationary(disc, forward, desired_state=v_d, beta=1.0), disc, v_d
+
+
+def test_stationary_linear_control_against_the_reduced_problem():
+    """``test/test_control.py:554-707``: the reference checks the KKT solve against an
+    independent minimisation of the reduced functional (L-BFGS through tlm_adjoint) with the
+    bars 1e-8 (state) and 1e-6 (control).  Here the reduced problem -- quadratic for the
+    linear state equation -- is solved exactly with dense algebra: same bars."""
+    ctl, disc, v_d = _stationary_reference_problem()
+    ksp = ctl.linear_solve(solver_parameters=KAT_SP, lambda_v_bounds=(0.5, 2.0),
+                           backend=common.OracleBackend(schur=(40, 0.02, 2.2)))
+    assert ksp.reason > 0
+    inner = np.setdiff1d(np.arange(disc.n_dofs), disc.boundary)
+    M = disc.M.toarray()[np.ix_(inner, inner)]
+    A = (disc.K + 2.0 * disc.M).toarray()[np.ix_(inner, inner)]
+    S = np.linalg.solve(A, M)                       # u = S m
+    r = v_d(disc.coords)[inner]
+    beta = 1.0                                      # J = |u - r|^2_M + beta^2 |m|^2_M
+    m = np.linalg.solve(S.T @ M @ S + beta**2 * M, S.T @ (M @ r))
+    u = S @ m
+
+    def l2(e):
+        return np.sqrt(abs(e @ (M @ e)))
+    assert l2(ctl._v[inner] - u) < 1.0e-8           # test_control.py:701
+    assert l2(ctl._zeta[inner] / beta - m) < 1.0e-6  # test_control.py:706
+    assert np.all(ctl._v[disc.boundary] == 0.0) and np.all(ctl._zeta[disc.boundary] == 0.0)
+
+
+def test_stationary_picard_loop_with_the_oracle():
+    """``Stationary.non_linear_solve`` (``control.py:640-760``) on the reference's non-linear
+    reaction problem: the residual norms fall monotonically and the fixed point satisfies the
+    Picard optimality system ``M v + D(v)^T zeta = M v_d``, ``D(v) v = M zeta / beta``."""
+    ctl, disc, v_d = _stationary_reference_problem(nonlinear=True)
+    norms = ctl.non_linear_solve(solver_parameters=KAT_SP, lambda_v_bounds=(0.5, 2.0),
+                                 max_non_linear_iter=30, relative_non_linear_tol=1.0e-10,
+                                 backend=common.OracleBackend(schur=(40, 0.02, 2.2)))
+    assert norms[-1] <= 1.0e-10 * norms[0]
+    assert all(b < a for a, b in zip(norms, norms[1:]))
+    D = ctl.construct_D_v(ctl._v)
+    r0 = disc.M @ v_d(disc.coords) - disc.M @ ctl._v - D.T @ ctl._zeta
+    r1 = -(D @ ctl._v) + disc.M @ ctl._zeta
+    r0[disc.boundary] = r1[disc.boundary] = 0.0
+    assert max(np.abs(r0).max(), np.abs(r1).max()) < 1.0e-9
+
+
+@pytest.mark.gpu
+def test_stationary_drivers_on_the_gpu():
+    from control_amd.control import GpuBackend
+    for nonlinear in (False, True):
+        ctl, disc, _ = _stationary_reference_problem(nonlinear)
+        ref, _, _ = _stationary_reference_problem(nonlinear)
+        for c, be in ((ctl, GpuBackend(schur=(40, 0.02, 2.2))),
+                      (ref, common.OracleBackend(schur=(40, 0.02, 2.2)))):
+            if nonlinear:
+                c.non_linear_solve(solver_parameters=KAT_SP, lambda_v_bounds=(0.5, 2.0),
+                                   max_non_linear_iter=30, relative_non_linear_tol=1.0e-10,
+                                   backend=be)
+            else:
+                c.linear_solve(solver_parameters=KAT_SP, lambda_v_bounds=(0.5, 2.0), backend=be)
+        assert np.abs(ctl._v - ref._v).max() < 1e-10
+        assert np.abs(ctl._zeta - ref._zeta).max() < 1e-9
