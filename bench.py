@@ -239,7 +239,10 @@ def main():
     print("[bench] assembling the synthetic system", file=sys.stderr, flush=True)
     p = build_problem(args)
     comm = make_comm(rank, world, local_rank) if world > 1 else None
-    gsys = common.gpu_system(p, device=local_rank, comm=comm)
+    # KKT_DEVICE pins every rank to one GPU (rehearsal of the N > 1 path on a one-GPU box,
+    # with KKT_TRANSPORT=gloo); production: one GPU per local rank
+    device = int(os.environ.get("KKT_DEVICE", local_rank))
+    gsys = common.gpu_system(p, device=device, comm=comm)
     lib, h = gsys._lib, gsys.handle
     gpc = common.gpu_pc(p, p["mass"], p["schur"])
     gsys._set_pc(gpc)
@@ -316,6 +319,7 @@ def main():
             "preconditioner": (f"block Schur: mass Chebyshev {p['mass']}, "
                                f"Schur Chebyshev {p['schur']} (its, emin, emax)"),
             "parallelism": f"time-block rows over {world} GPU(s)",
+            "transport": (os.environ.get("KKT_TRANSPORT", "rccl") if world > 1 else "none"),
             "pc_apply_ms": pc_ms, "kkt_apply_ms": spmv_ms},
         "roofline": {
             "kernel": "kkt_spmv_rows (fused block-row SpMV of the KKT operator)",
@@ -329,7 +333,7 @@ def main():
             "note": "algorithmic bytes = SURVEY 8d mode-" + args.mode +
                     " CSR formula; index arrays are shared on the device"},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (contract)
         out["cpu_baseline"] = cpu_baseline(p, args)
     print(json.dumps(out))
 

@@ -10,7 +10,7 @@ This module only bootstraps a transport for a ``MultiBlockSystem``:
 * ``CallbackComm``-- host-staged transport over any pair of Python functions
                     (``multiprocessing`` pipes in the tests, ``torch.distributed``/gloo).
 
-No PyTorch is imported here.
+PyTorch is imported only by the gloo rehearsal transport.
 """
 from __future__ import annotations
 
@@ -22,7 +22,8 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["RcclComm", "CallbackComm", "PipeTransport", "make_comm", "shard_range"]
+__all__ = ["RcclComm", "CallbackComm", "PipeTransport", "GlooTransport", "make_comm",
+           "shard_range"]
 
 
 def shard_range(m, rank, world):
@@ -162,6 +163,42 @@ class PipeTransport:
         return None
 
 
+class GlooTransport:
+    """allreduce / sendrecv over ``torch.distributed`` with the gloo backend (host-staged).
+    A rehearsal transport: it lets ``bench.py --gpus N`` run with all ranks on ONE GPU
+    (``KKT_TRANSPORT=gloo``), which RCCL refuses; the production transport is RCCL."""
+
+    def __init__(self, rank, world):
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        self._torch, self._dist = torch, dist
+        self.rank, self.world = rank, world
+
+    def allreduce(self, buf, op):
+        t = self._torch.from_numpy(np.ascontiguousarray(buf))
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM if op == 0
+                              else self._dist.ReduceOp.MAX)
+        buf[:] = t.numpy()
+
+    def sendrecv(self, send, dst, n_recv, src):
+        reqs, out = [], None
+        if dst is not None and dst >= 0 and send is not None:
+            reqs.append(self._dist.isend(self._torch.from_numpy(np.array(send, copy=True)), dst))
+        if src is not None and src >= 0 and n_recv > 0:
+            t = self._torch.empty(n_recv, dtype=self._torch.float64)
+            reqs.append(self._dist.irecv(t, src))
+            out = t
+        for r in reqs:
+            r.wait()
+        return None if out is None else out.numpy()
+
+
 def make_comm(rank, world, local_rank=0):
-    """Production transport for ``bench.py`` under ``torch.distributed.run``."""
+    """Transport for ``bench.py`` under ``torch.distributed.run``: RCCL over xGMI, or the
+    gloo rehearsal transport when ``KKT_TRANSPORT=gloo``."""
+    if os.environ.get("KKT_TRANSPORT", "rccl") == "gloo":
+        tr = GlooTransport(rank, world)
+        return CallbackComm(rank, world, tr.allreduce, tr.sendrecv)
     return RcclComm(rank, world)
