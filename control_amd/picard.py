@@ -1,4 +1,4 @@
-"""Picard outer loop of instationary Navier-Stokes control (backward Euler).
+"""Picard outer loop of instationary Navier-Stokes control (BE and CN).
 
 Host-side mirror of ``Control.Instationary.incompressible_non_linear_solve``
 (``control/control.py:4886-5232``): evaluate the non-linear residual at the current iterate
@@ -44,6 +44,7 @@ class NavierStokesControl:
     f: np.ndarray                        # (n_t, n_v)
     v_0: np.ndarray = None               # (n_v,), zero when omitted
     t_0: float = 0.0
+    CN: bool = False                     # Crank-Nicolson instead of backward Euler
 
     @property
     def tau(self):
@@ -58,6 +59,18 @@ class NavierStokesControl:
         """The same form on the pressure space (``control.py:3783-3785``)."""
         return _same_structure_sum(self.disc.K_p, [(self.nu, self.disc.K_p),
                                                    (1.0, self.disc.convection_p(w))])
+
+
+def _apply_T_1(b):            # preconditioner.py:33-45
+    out = b.copy()
+    out[:-1] += b[1:]
+    return out
+
+
+def _apply_T_2(b):            # preconditioner.py:48-60
+    out = b.copy()
+    out[1:] += b[:-1]
+    return out
 
 
 def _same_structure_sum(like, terms):
@@ -80,6 +93,27 @@ def non_linear_res_eval(pb: NavierStokesControl, D, v, zeta, p, mu):
     M, B = th.M_v, th.B
     BT = sp.csr_matrix(B.T)
     v_0 = np.zeros(th.n_v) if pb.v_0 is None else pb.v_0
+    if pb.CN:
+        # control.py:2621-2808 + 5043-5082: row i couples the levels i and i + 1; v[0] is the
+        # initial condition, zeta[n_t - 1] = 0; mu, p live on the n_t - 1 intervals
+        m, h = n_t - 1, 0.5 * tau
+        r00 = np.zeros((m, th.n_v))
+        r01 = np.zeros((m, th.n_v))
+        for i in range(m):
+            r00[i] = (h * (M @ (pb.v_d[i] + pb.v_d[i + 1])) - h * (M @ (v[i] + v[i + 1]))
+                      - (h * (D[i].T @ zeta[i]) + M @ zeta[i])
+                      - (h * (D[i + 1].T @ zeta[i + 1]) - M @ zeta[i + 1])
+                      - tau * (BT @ mu[i]))
+            r01[i] = (h * (M @ (pb.f[i] + pb.f[i + 1]))
+                      - (h * (D[i] @ v[i]) - M @ v[i])
+                      - (h * (D[i + 1] @ v[i + 1]) + M @ v[i + 1])
+                      + (h / beta) * (M @ (zeta[i] + zeta[i + 1]))
+                      - tau * (BT @ p[i]))
+        r00[:, th.boundary_v] = 0.0
+        r01[:, th.boundary_v] = 0.0
+        r10 = np.stack([-(B @ v[i + 1]) for i in range(m)])
+        r11 = np.stack([-(B @ zeta[i]) for i in range(m)])
+        return r00, r01, r10, r11
     r00 = np.zeros((n_t, th.n_v))
     r01 = np.zeros((n_t, th.n_v))
     for i in range(n_t):
@@ -120,45 +154,55 @@ class GpuLinearSolver:
     def _blocks(self, D, Dp):
         th, pb = self.pb.disc, self.pb
         return instationary_incompressible_blocks(th.M_v, list(D), th.B, th.M_p, list(Dp),
-                                                  pb.tau, pb.beta, pb.n_t, False)
+                                                  pb.tau, pb.beta, pb.n_t, pb.CN)
 
     def _build(self, bl):
         from .multiblock import (ChebSpec, ConstantNullspace, DirichletBCNullspace,
                                  MultiBlockSystem, SchurPC, StokesPC)
-        th, pb, m = self.pb.disc, self.pb, self.pb.n_t
+        th, pb, m = self.pb.disc, self.pb, bl["m"]
         nsv = DirichletBCNullspace(th.boundary_v)
+        kw = dict(sub_n_blocks_00_0=m, sub_n_blocks_11_0=m) if pb.CN else {}
         self.outer = MultiBlockSystem(
             th.n_v, th.n_p, *bl["outer"], n_blocks_00=2 * m, n_blocks_11=2 * m,
             nullspace_0=(nsv,) * (2 * m),
-            nullspace_1=tuple(ConstantNullspace() for _ in range(2 * m)), device=self.device)
+            nullspace_1=tuple(ConstantNullspace() for _ in range(2 * m)), device=self.device,
+            CN=pb.CN, **kw)
         self.inner = MultiBlockSystem(th.n_v, th.n_v, *bl["inner"], n_blocks_00=m,
                                       n_blocks_11=m, nullspace_0=(nsv,) * m,
-                                      nullspace_1=(nsv,) * m, device=self.device)
+                                      nullspace_1=(nsv,) * m, device=self.device, CN=pb.CN)
         self.comm = MultiBlockSystem(th.n_p, th.n_p, *bl["commutator"], n_blocks_00=m,
                                      n_blocks_11=m, device=self.device)
         s = self.specs
-        inner_pc = SchurPC(kind="BE", M=th.M_v, beta=pb.beta, bc_nodes=th.boundary_v,
+        inner_pc = SchurPC(kind="CN" if pb.CN else "BE", M=th.M_v, beta=pb.beta, bc_nodes=th.boundary_v,
                            mass=ChebSpec(*s["mass"]), schur=ChebSpec(*s["schur"]), n_t=pb.n_t,
                            tau=pb.tau)
         self.pc = StokesPC(inner=self.inner, inner_pc=inner_pc, commutator=self.comm, B=th.B,
                            K_p=th.K_p, M_p=th.M_p, kp=ChebSpec(*s["kp"]), mp=ChebSpec(*s["mp"]),
-                           n_p_blocks=m, b_scale=pb.tau, post_scale=1.0 / pb.tau**2)
+                           n_p_blocks=m, b_scale=pb.tau, post_scale=1.0 / pb.tau**2, cn=pb.CN)
 
     def _update(self, bl):
-        """Blocks that depend on the linearisation point: ``tau D_i^T + M`` / ``tau D_i + M``
-        on the diagonal of ``block_01_int`` / ``block_10_int`` (``control.py:3806-3808``),
-        their copies inside the outer ``block_00``, and the pressure-space analogues."""
-        m = self.pb.n_t
+        """Blocks that carry the linearised operator: all of ``block_01_int`` / ``block_10_int``
+        (``control.py:3806-3808`` BE, ``3851-3885`` CN; the pure mass couplings among them are
+        re-sent unchanged), their copies inside the outer ``block_00``, and the
+        pressure-space analogues."""
+        m = bl["m"]
         i00, i01, i10, i11 = bl["inner"]
         c00, c01, c10, c11 = bl["commutator"]
-        for i in range(m):
-            self.inner.update_block_values(1, i, i, i01[(i, i)])
-            self.inner.update_block_values(2, i, i, i10[(i, i)])
-            self.outer.update_block_values(0, i, m + i, i01[(i, i)])
-            self.outer.update_block_values(0, m + i, i, i10[(i, i)])
-            self.comm.update_block_values(1, i, i, c01[(i, i)])
-            self.comm.update_block_values(2, i, i, c10[(i, i)])
-            self.uploads += 6
+        for (i, j), A in i01.items():          # -> outer block_00 (i, m + j)
+            if A is not None:
+                self.inner.update_block_values(1, i, j, A)
+                self.outer.update_block_values(0, i, m + j, A)
+                self.uploads += 2
+        for (i, j), A in i10.items():          # -> outer block_00 (m + i, j)
+            if A is not None:
+                self.inner.update_block_values(2, i, j, A)
+                self.outer.update_block_values(0, m + i, j, A)
+                self.uploads += 2
+        for q, blk in ((1, c01), (2, c10)):
+            for (i, j), A in blk.items():
+                if A is not None:
+                    self.comm.update_block_values(q, i, j, A)
+                    self.uploads += 1
 
     def linear_solve(self, D, Dp, b_0, b_1):
         bl = self._blocks(D, Dp)
@@ -184,11 +228,13 @@ def incompressible_non_linear_solve(pb: NavierStokesControl, linear_solver, *,
     Returns a dict with the converged fields, the non-linear residual norms (``norm_0``
     first) and the linear iteration counts."""
     th, n_t, tau = pb.disc, pb.n_t, pb.tau
-    z = lambda n: np.zeros((n_t, n))    # noqa: E731
-    v = z(th.n_v) if v is None else np.array(v, dtype=np.float64)
-    zeta = z(th.n_v) if zeta is None else np.array(zeta, dtype=np.float64)
-    p = z(th.n_p) if p is None else np.array(p, dtype=np.float64)
-    mu = z(th.n_p) if mu is None else np.array(mu, dtype=np.float64)
+    m = n_t - 1 if pb.CN else n_t
+    v = np.zeros((n_t, th.n_v)) if v is None else np.array(v, dtype=np.float64)
+    zeta = np.zeros((n_t, th.n_v)) if zeta is None else np.array(zeta, dtype=np.float64)
+    p = np.zeros((m, th.n_p)) if p is None else np.array(p, dtype=np.float64)
+    mu = np.zeros((m, th.n_p)) if mu is None else np.array(mu, dtype=np.float64)
+    if pb.CN:
+        v[0] = np.zeros(th.n_v) if pb.v_0 is None else pb.v_0   # :4961-4962
     zeta[n_t - 1] = 0.0                                          # :4963
 
     def evaluate():
@@ -204,15 +250,23 @@ def incompressible_non_linear_solve(pb: NavierStokesControl, linear_solver, *,
     k = 0
     while norm_k > relative_non_linear_tol * norm_0 and norm_k > absolute_non_linear_tol:
         Dp = [pb.D_p(v[i]) for i in range(n_t)]
+        s10, s11 = tau * r10, tau * r11                          # :5102-5105
+        if pb.CN:    # the linear solve transforms the rows it is given (control.py:4266-4269)
+            r00, r01 = _apply_T_1(r00), _apply_T_2(r01)
+            s10, s11 = _apply_T_2(s10), _apply_T_1(s11)
         b_0 = np.concatenate([r00, r01])
-        b_1 = np.concatenate([tau * r10, tau * r11])             # :5102-5105
+        b_1 = np.concatenate([s10, s11])
         u_0, u_1, its = linear_solver.linear_solve(D, Dp, b_0, b_1)
         lin_its.append(its)
-        v += u_0[:n_t]                                           # :5127-5147
-        zeta += u_0[n_t:]
+        if pb.CN:                # unknown block i: v at level i + 1, zeta at level i
+            v[1:] += u_0[:m]
+            zeta[:m] += u_0[m:]
+        else:
+            v += u_0[:m]                                         # :5127-5147
+            zeta += u_0[m:]
         zeta[:, th.boundary_v] = 0.0
-        mu += u_1[:n_t]          # pressure blocks: mu with the v rows, p with the zeta rows
-        p += u_1[n_t:]
+        mu += u_1[:m]            # pressure blocks: mu with the v rows, p with the zeta rows
+        p += u_1[m:]
         D, (r00, r01, r10, r11), norm_k = evaluate()
         norms.append(norm_k)
         k += 1

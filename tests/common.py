@@ -126,7 +126,7 @@ NS_SOLVER_PARAMETERS = {"linear_solver": "fgmres", "fgmres_restart": 10,
                         "absolute_tolerance": 0.0, "monitor_convergence": False}
 
 
-def navier_stokes_problem(n=4, n_t=4, nu=0.1, beta=1.0e-2, T=2.0):
+def navier_stokes_problem(n=4, n_t=4, nu=0.1, beta=1.0e-2, T=2.0, CN=False):
     """A small instance shaped like ``test/test_control.py:4160-4270`` (P2-P1 on
     ``RectangleMesh(n, n, 2, 2)``, Picard convection, zero force and initial state) with a
     smooth desired state that vanishes on the boundary."""
@@ -139,7 +139,7 @@ def navier_stokes_problem(n=4, n_t=4, nu=0.1, beta=1.0e-2, T=2.0):
         np.sin(0.5 * np.pi * X) ** 2 * np.sin(np.pi * Y),
         -np.sin(np.pi * X) * np.sin(0.5 * np.pi * Y) ** 2]) for i in range(n_t)])
     return NavierStokesControl(disc=th, nu=nu, beta=beta, n_t=n_t, T=T, v_d=v_d,
-                               f=np.zeros((n_t, th.n_v)))
+                               f=np.zeros((n_t, th.n_v)), CN=CN)
 
 
 class OracleLinearSolver:
@@ -151,17 +151,19 @@ class OracleLinearSolver:
     def linear_solve(self, D, Dp, b_0, b_1):
         from control_amd.blocks import instationary_incompressible_blocks
         from oracle import kkt_oracle as ko
-        pb, th, m, s = self.pb, self.pb.disc, self.pb.n_t, self.specs
+        pb, th, s = self.pb, self.pb.disc, self.specs
         bl = instationary_incompressible_blocks(th.M_v, list(D), th.B, th.M_p, list(Dp),
-                                                pb.tau, pb.beta, pb.n_t, False)
+                                                pb.tau, pb.beta, pb.n_t, pb.CN)
+        m = bl["m"]
+        kw = dict(sub_n_blocks_00_0=m, sub_n_blocks_11_0=m) if pb.CN else {}
         osys = ko.OracleSystem(
             th.n_v, th.n_p, *bl["outer"], n_blocks_00=2 * m, n_blocks_11=2 * m,
             nullspace_0=tuple(ko.DirichletBCNullspace(th.boundary_v) for _ in range(2 * m)),
-            nullspace_1=tuple(ko.ConstantNullspace() for _ in range(2 * m)))
+            nullspace_1=tuple(ko.ConstantNullspace() for _ in range(2 * m)), CN=pb.CN, **kw)
         opc = ko.pc_instationary_incompressible(
             th.M_v, bl["inner"], th.B, th.M_p, th.K_p, bl["commutator"], pb.n_t, pb.tau,
             pb.beta, th.boundary_v, ko.ChebSpec(*s["mass"]), ko.ChebSpec(*s["schur"]),
-            ko.ChebSpec(*s["kp"]), ko.ChebSpec(*s["mp"]))
+            ko.ChebSpec(*s["kp"]), ko.ChebSpec(*s["mp"]), CN=pb.CN)
         u_0, u_1 = np.zeros_like(b_0), np.zeros_like(b_1)
         res = osys.solve(u_0, u_1, b_0, b_1, solver_parameters=self.sp, pc_fn=opc)
         return u_0, u_1, res.its
