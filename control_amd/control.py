@@ -280,6 +280,85 @@ class Instationary:
             self.set_zeta(zeta)
         return ksp
 
+    def non_linear_res_eval(self, v_old, zeta_old, v_0, v_d, f):
+        """``control.py:2442-2810``: residual rows of the (Picard-linearised) optimality system
+        at ``(v_old, zeta_old)``, all ``n_t`` levels given; BE: ``n_t`` rows, CN: ``n_t - 1``."""
+        disc, n_t, beta, CN = self._disc, self._n_t, self._beta, self._CN
+        M, nodes = disc.M, disc.boundary
+        t_0, _, tau = self._times()
+        D = [sp.csr_matrix(self._forward(v_old[i], t_0 + i * tau)) for i in range(n_t)]
+        if CN:
+            m, h = n_t - 1, 0.5 * tau
+            r0 = np.zeros((m, disc.n_dofs))
+            r1 = np.zeros((m, disc.n_dofs))
+            for i in range(m):
+                r0[i] = (h * (v_d[i] + v_d[i + 1]) - h * (M @ (v_old[i] + v_old[i + 1]))
+                         - (h * (D[i].T @ zeta_old[i]) + M @ zeta_old[i])
+                         - (h * (D[i + 1].T @ zeta_old[i + 1]) - M @ zeta_old[i + 1]))
+                r1[i] = (h * (f[i] + f[i + 1])
+                         - (h * (D[i] @ v_old[i]) - M @ v_old[i])
+                         - (h * (D[i + 1] @ v_old[i + 1]) + M @ v_old[i + 1])
+                         + (h / beta) * (M @ (zeta_old[i] + zeta_old[i + 1])))
+        else:
+            r0 = np.zeros((n_t, disc.n_dofs))
+            r1 = np.zeros((n_t, disc.n_dofs))
+            D_0 = sp.csr_matrix(self._forward(v_0, t_0))
+            for i in range(n_t):
+                Dz = tau * (D[i].T @ zeta_old[i]) + M @ zeta_old[i]
+                r0[i] = (tau * v_d[i] - tau * (M @ v_old[i]) - Dz + M @ zeta_old[i + 1]
+                         if i < n_t - 1 else -Dz)
+                Dv = tau * (D[i] @ v_old[i]) + M @ v_old[i]
+                r1[i] = (tau * (D_0 @ v_0) + M @ v_0 - Dv if i == 0 else
+                         tau * f[i] + M @ v_old[i - 1] - Dv + (tau / beta) * (M @ zeta_old[i]))
+        r0[:, nodes] = 0.0
+        r1[:, nodes] = 0.0
+        return r0, r1
+
+    def non_linear_solve(self, *, P=None, solver_parameters=None, lambda_v_bounds=None,
+                         max_non_linear_iter=10, relative_non_linear_tol=1.0e-5,
+                         absolute_non_linear_tol=1.0e-8, print_error_non_linear=False,
+                         backend=None):
+        """``control.py:3377-3560``: Picard loop around ``linear_solve``; returns the residual
+        norms (initial one first)."""
+        disc, n_t, CN = self._disc, self._n_t, self._CN
+        v_0 = (np.zeros(disc.n_dofs) if self._initial_condition is None
+               else np.asarray(self._initial_condition(disc.coords), dtype=np.float64))
+        v_old, zeta_old = self._v.copy(), self._zeta.copy()
+        if CN:
+            v_old[0] = v_0                                           # control.py:3425-3426
+        zeta_old[n_t - 1] = 0.0
+        f, v_d = self.construct_f(), self.construct_v_d()
+
+        def evaluate():
+            r0, r1 = self.non_linear_res_eval(v_old, zeta_old, v_0, v_d, f)
+            return r0, r1, float(np.sqrt(np.vdot(r0, r0) + np.vdot(r1, r1)))
+        rhs_0, rhs_1, norm_0 = evaluate()
+        norm_k, k, norms = norm_0, 0, [norm_0]
+        while norm_k > relative_non_linear_tol * norm_0 and norm_k > absolute_non_linear_tol:
+            self._v = v_old          # linear_solve linearises at self._v (control.py:2886)
+            self.linear_solve(P=P, solver_parameters=solver_parameters,
+                              lambda_v_bounds=lambda_v_bounds, v_d=rhs_0, f=rhs_1,
+                              backend=backend)
+            v_old = v_old + self._v
+            for i in range(n_t):                                     # :3490-3493
+                v_old[i, disc.boundary] = self._bc_values(i)[disc.boundary]
+            if CN:
+                v_old[0] = v_0
+                v_old[0, disc.boundary] = self._bc_values(0)[disc.boundary]
+            zeta_old = zeta_old + self._zeta
+            zeta_old[:, disc.boundary] = 0.0
+            self.set_v(v_old)
+            self.set_zeta(zeta_old)
+            rhs_0, rhs_1, norm_k = evaluate()
+            norms.append(norm_k)
+            k += 1
+            if print_error_non_linear:
+                print(f"Non-linear solver: iteration {k:d}, non-linear residual norm "
+                      f"{norm_k:.16e}")
+            if k + 1 > max_non_linear_iter:
+                break
+        return norms
+
     def set_p(self, p):              # control.py:1858-1865
         self._p = np.array(p, dtype=np.float64)
 

@@ -175,3 +175,53 @@ def test_stationary_drivers_on_the_gpu():
                 c.linear_solve(solver_parameters=KAT_SP, lambda_v_bounds=(0.5, 2.0), backend=be)
         assert np.abs(ctl._v - ref._v).max() < 1e-10
         assert np.abs(ctl._zeta - ref._zeta).max() < 1e-9
+
+
+# ------------------------------------------------------ Instationary.non_linear_solve
+
+def _reaction_heat_control(CN, n=8, n_t=5):
+    """Instationary version of the reference's non-linear reaction problem
+    (``test/test_control.py:715-719``): ``forward_form = grad-grad + (2 + 0.5 v_old^2) mass``."""
+    from control_amd.control import Instationary
+    from control_amd.fem import unit_square_p1
+    disc = unit_square_p1(n)
+
+    def forward(v_old, t):
+        return disc.K + disc.weighted_mass(
+            lambda lam, cells: 2.0 + 0.5 * (v_old[cells] @ lam.T) ** 2)
+
+    def v_d(X, t):
+        return (1.0 + t) * np.sin(np.pi * X[:, 0]) * np.sin(np.pi * X[:, 1]) * np.exp(X[:, 0])
+    return Instationary(disc, forward, desired_state=v_d, beta=1.0e-2, CN=CN, n_t=n_t,
+                        time_interval=(0.0, 1.0)), disc
+
+
+@pytest.mark.parametrize("CN", [False, True])
+def test_instationary_picard_loop_with_the_oracle(CN):
+    ctl, disc = _reaction_heat_control(CN)
+    norms = ctl.non_linear_solve(solver_parameters=KAT_SP, lambda_v_bounds=(0.5, 2.0),
+                                 max_non_linear_iter=30, relative_non_linear_tol=1.0e-9,
+                                 absolute_non_linear_tol=0.0,
+                                 backend=common.OracleBackend(schur=(40, 0.02, 2.2)))
+    assert norms[-1] <= 1.0e-9 * norms[0]
+    assert all(b < a for a, b in zip(norms[1:], norms[2:]))
+    # the driver's own residual at the returned fields is the last norm it reported
+    r0, r1 = ctl.non_linear_res_eval(ctl._v, ctl._zeta, np.zeros(disc.n_dofs),
+                                     ctl.construct_v_d(), ctl.construct_f())
+    assert abs(np.sqrt(np.vdot(r0, r0) + np.vdot(r1, r1)) - norms[-1]) <= 1e-12 + 1e-6 * norms[-1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("CN", [False, True])
+def test_instationary_picard_loop_on_the_gpu(CN):
+    from control_amd.control import GpuBackend
+    out = []
+    for be in (GpuBackend(schur=(40, 0.02, 2.2)), common.OracleBackend(schur=(40, 0.02, 2.2))):
+        ctl, _ = _reaction_heat_control(CN)
+        norms = ctl.non_linear_solve(solver_parameters=KAT_SP, lambda_v_bounds=(0.5, 2.0),
+                                     max_non_linear_iter=30, relative_non_linear_tol=1.0e-9,
+                                     absolute_non_linear_tol=0.0, backend=be)
+        out.append((norms, ctl._v.copy(), ctl._zeta.copy()))
+    assert len(out[0][0]) == len(out[1][0])
+    assert np.abs(out[0][1] - out[1][1]).max() < 1e-9
+    assert np.abs(out[0][2] - out[1][2]).max() < 1e-9
