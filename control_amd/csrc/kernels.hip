@@ -111,9 +111,13 @@ __device__ __forceinline__ void load_cols(gci_p p, int (&c)[R]) {
     }
 }
 
-template <int R, bool NT, int W, bool COH>
-__device__ __forceinline__ void accumulate_exact(const RowOp &op, const Bases &bases,
-                                                 size_t base, double (&acc)[R]) {
+// `terms(t)` yields the t-th SpmvTerm of the op: from the descriptor in memory, or unpacked
+// from a wave-held copy (persistent programs), so that no descriptor array is indexed
+// dynamically in registers.
+template <int R, bool NT, int W, bool COH, class TermFn>
+__device__ __forceinline__ void accumulate_exact(const RowOp &op, const TermFn &terms,
+                                                 const Bases &bases, size_t base,
+                                                 double (&acc)[R]) {
     constexpr int C = 64 * R;
     constexpr int CH = 8;                       // slots per register chunk
     constexpr int NCH = (W + CH - 1) / CH;
@@ -124,14 +128,15 @@ __device__ __forceinline__ void accumulate_exact(const RowOp &op, const Bases &b
     const int nterms = op.nterms;
     double vn[CH][R];                           // values of the next (term, chunk)
     {
-        const gcd_p vp = (gcd_p)op.t[0].vals + base;
+        const gcd_p vp = (gcd_p)terms(0).vals + base;
 #pragma unroll
         for (int k = 0; k < (W < CH ? W : CH); ++k) load_vals<R, NT>(vp + (size_t)k * C, vn[k]);
     }
     for (int t = 0; t < nterms; ++t) {
-        const gcd_p x = resolve(op.t[t].x, bases);
-        const gcd_p vcur = (gcd_p)op.t[t].vals + base;
-        const gcd_p vnext = (t + 1 < nterms) ? (gcd_p)op.t[t + 1].vals + base : vcur;
+        const SpmvTerm tm = terms(t);
+        const gcd_p x = resolve(tm.x, bases);
+        const gcd_p vcur = (gcd_p)tm.vals + base;
+        const gcd_p vnext = (t + 1 < nterms) ? (gcd_p)terms(t + 1).vals + base : vcur;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             constexpr int dummy = 0;
@@ -170,31 +175,75 @@ __device__ __forceinline__ void accumulate_exact(const RowOp &op, const Bases &b
     }
 }
 
-template <int R, bool NT, bool COH>
-__device__ __forceinline__ void accumulate_generic(const RowOp &op, const Bases &bases,
-                                                   size_t base, int w, double (&acc)[R]) {
+template <int R, bool NT, bool COH, class TermFn>
+__device__ __forceinline__ void accumulate_generic(const RowOp &op, const TermFn &terms,
+                                                   const Bases &bases, size_t base, int w,
+                                                   double (&acc)[R]) {
     constexpr int C = 64 * R;
     const gci_p colp = (gci_p)op.col + base;
     const int nterms = op.nterms;
-    for (int t = 0; t < nterms; ++t) {
-        const gcd_p vp = (gcd_p)op.t[t].vals + base;
-        const gcd_p x = resolve(op.t[t].x, bases);
-#pragma unroll 4
-        for (int k = 0; k < w; ++k) {
-            int c[R];
-            double v[R];
-            load_cols<R>(colp + (size_t)k * C, c);
-            load_vals<R, NT>(vp + (size_t)k * C, v);
+    if constexpr (COH) {
+        // Persistent programs are latency-bound: a phase is a chain of dependent round trips
+        // (indices -> gathers through L2 -> fma).  Whole chunks of KC slots are in flight at
+        // once and the next chunk's indices travel with the current chunk's gathers; slots
+        // past the slice width re-read the last valid slot with a zero value
+        // (fma(0, x, acc) == acc), so there is no branch inside the chunk.
+        constexpr int KC = 12;
+        for (int t = 0; t < (w > 0 ? nterms : 0); ++t) {
+            const SpmvTerm tm = terms(t);
+            const gcd_p vp = (gcd_p)tm.vals + base;
+            const gcd_p x = resolve(tm.x, bases);
+            int c[KC][R];
 #pragma unroll
-            for (int q = 0; q < R; ++q) acc[q] = __builtin_fma(v[q], ldv<COH>(x + c[q]), acc[q]);
+            for (int k = 0; k < KC; ++k)
+                load_cols<R>(colp + (size_t)(k < w ? k : w - 1) * C, c[k]);
+            for (int k0 = 0; k0 < w; k0 += KC) {
+                double v[KC][R], xv[KC][R];
+#pragma unroll
+                for (int k = 0; k < KC; ++k) {
+                    const int kk = k0 + k < w ? k0 + k : w - 1;
+                    load_vals<R, NT>(vp + (size_t)kk * C, v[k]);
+#pragma unroll
+                    for (int q = 0; q < R; ++q) xv[k][q] = ldv<COH>(x + c[k][q]);
+                }
+                if (k0 + KC < w) {
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) {
+                        const int kk = k0 + KC + k < w ? k0 + KC + k : w - 1;
+                        load_cols<R>(colp + (size_t)kk * C, c[k]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < KC; ++k)
+#pragma unroll
+                    for (int q = 0; q < R; ++q)
+                        acc[q] = __builtin_fma(k0 + k < w ? v[k][q] : 0.0, xv[k][q], acc[q]);
+            }
+        }
+    } else {
+        for (int t = 0; t < nterms; ++t) {
+            const SpmvTerm tm = terms(t);
+            const gcd_p vp = (gcd_p)tm.vals + base;
+            const gcd_p x = resolve(tm.x, bases);
+#pragma unroll 4
+            for (int k = 0; k < w; ++k) {
+                int c[R];
+                double v[R];
+                load_cols<R>(colp + (size_t)k * C, c);
+                load_vals<R, NT>(vp + (size_t)k * C, v);
+#pragma unroll
+                for (int q = 0; q < R; ++q)
+                    acc[q] = __builtin_fma(v[q], ldv<COH>(x + c[q]), acc[q]);
+            }
         }
     }
 }
 
 // WFIX > 0: the launcher knows every slice of every RowOp in the launch has width WFIX
 // (structured meshes: 7 for 2-D P1, 15 for 3-D P1) and picks the kernel unrolled for it.
-template <int R, bool NT, int WFIX, bool COH>
-__device__ __forceinline__ void rowops_body(const RowOp &op, const Bases &bases, const int s) {
+template <int R, bool NT, int WFIX, bool COH, class TermFn>
+__device__ __forceinline__ void rowops_body(const RowOp &op, const TermFn &terms,
+                                            const Bases &bases, const int s) {
     const int lane = threadIdx.x & 63;
     if (s >= op.nslices) return;
     constexpr int C = 64 * R;
@@ -256,9 +305,9 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const Bases &bases,
     for (int q = 0; q < R; ++q) acc[q] = 0.0;
     if (op.nterms > 0) {
         if constexpr (WFIX > 0)
-            accumulate_exact<R, NT, WFIX, COH>(op, bases, base, acc);
+            accumulate_exact<R, NT, WFIX, COH>(op, terms, bases, base, acc);
         else
-            accumulate_generic<R, NT, COH>(op, bases, base, w, acc);
+            accumulate_generic<R, NT, COH>(op, terms, bases, base, w, acc);
     }
 
     const gd_p y = (gd_p)resolve(op.y, bases);
@@ -308,18 +357,23 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const Bases &bases,
 template <int R, int WFIX>
 __global__ __launch_bounds__(256) void kkt_spmv_rows(const RowOp *__restrict__ ops,
                                                      const Bases bases) {
-    rowops_body<R, true, WFIX, false>(ops[blockIdx.y], bases, blockIdx.x * 4 + (threadIdx.x >> 6));
+    const RowOp &op = ops[blockIdx.y];
+    rowops_body<R, true, WFIX, false>(op, [&](int t) { return op.t[t]; }, bases,
+                                      blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 template <int R, int WFIX>
 __global__ __launch_bounds__(256) void pc_rows(const RowOp *__restrict__ ops,
                                                const Bases bases) {
-    rowops_body<R, false, WFIX, false>(ops[blockIdx.y], bases, blockIdx.x * 4 + (threadIdx.x >> 6));
+    const RowOp &op = ops[blockIdx.y];
+    rowops_body<R, false, WFIX, false>(op, [&](int t) { return op.t[t]; }, bases,
+                                       blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 // One RowOp passed by value: the descriptor arrives with the kernel arguments instead of
 // through a dependent load -- one round trip less on the latency-bound sweep steps.
 template <int R, int WFIX>
 __global__ __launch_bounds__(256) void pc_row_step(const RowOp op, const Bases bases) {
-    rowops_body<R, false, WFIX, false>(op, bases, blockIdx.x * 4 + (threadIdx.x >> 6));
+    rowops_body<R, false, WFIX, false>(op, [&](int t) { return op.t[t]; }, bases,
+                                       blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 
@@ -340,6 +394,69 @@ __global__ __launch_bounds__(256) void pc_row_step(const RowOp op, const Bases b
 constexpr int FLAG_STRIDE = 32;                 // one 128-byte line per workgroup counter
 constexpr unsigned PROG_SPIN_LIMIT = 1u << 20;
 
+// A phase descriptor (one RowOp, < 512 bytes) is fetched by ONE wave-wide vector load --
+// lane l holds bytes 8l..8l+7 -- a whole phase ahead, and its fields are moved to scalar
+// registers with v_readlane.  Reading the descriptor field by field through the scalar
+// cache cost a dependent ~1 us miss per touched line and phase (scripts/prog_stamps.py).
+static_assert(sizeof(RowOp) <= 512 && sizeof(RowOp) % 8 == 0,
+              "RowOp must fit one 64 x 8-byte wave load");
+__device__ __forceinline__ unsigned long long rl64(unsigned long long v, int lane) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long load_desc_words(const RowOp *op) {
+    const KKT_GLOBAL unsigned long long *p = (const KKT_GLOBAL unsigned long long *)op;
+    const int lane = threadIdx.x & 63;
+    return (size_t)lane * 8 < sizeof(RowOp) ? p[lane] : 0ull;
+}
+// every field of a wave-held descriptor except the term array, as wave-uniform values
+#define KKT_U64(f) rl64(desc, (int)(offsetof(RowOp, f) / 8))
+#define KKT_U32(f) ((int32_t)(unsigned)(KKT_U64(f) >> (8 * (offsetof(RowOp, f) % 8))))
+#define KKT_UF64(f) __longlong_as_double((long long)KKT_U64(f))
+#define KKT_UPTR(T, f) ((T)(uintptr_t)KKT_U64(f))
+#define KKT_UVREF(f) VRef{(int64_t)KKT_U64(f.off), KKT_U32(f.base), 0}
+__device__ __forceinline__ RowOp unpack_desc_head(unsigned long long desc) {
+    RowOp op;
+    op.col = KKT_UPTR(const int32_t *, col);
+    op.slice_off = KKT_UPTR(const int32_t *, slice_off);
+    op.perm = KKT_UPTR(const int32_t *, perm);
+    op.nrows = KKT_U32(nrows);
+    op.nslices = KKT_U32(nslices);
+    op.nterms = KKT_U32(nterms);
+    op.mode = KKT_U32(mode);
+    op.uniform_w = KKT_U32(uniform_w);
+    op.y = KKT_UVREF(y);
+    op.y2 = KKT_UVREF(y2);
+    op.ca = KKT_UF64(ca);
+    op.cy = KKT_UF64(cy);
+    op.cz = KKT_UF64(cz);
+    op.yin = KKT_UVREF(yin);
+    op.z = KKT_UVREF(z);
+    op.rowmask = KKT_UPTR(const uint8_t *, rowmask);
+    op.mx = KKT_UVREF(mx);
+    op.malpha = KKT_UF64(malpha);
+    op.b = KKT_UVREF(b);
+    op.pkm1 = KKT_UVREF(pkm1);
+    op.pk = KKT_UVREF(pk);
+    op.dinv = KKT_UPTR(const double *, dinv);
+    op.c1 = KKT_UF64(c1);
+    op.c2 = KKT_UF64(c2);
+    op.c3 = KKT_UF64(c3);
+    op.post1 = KKT_UF64(post1);
+    op.post2 = KKT_UF64(post2);
+    return op;
+}
+__device__ __forceinline__ SpmvTerm unpack_desc_term(unsigned long long desc, int t) {
+    const int w0 = (int)(offsetof(RowOp, t) / 8) + t * (int)(sizeof(SpmvTerm) / 8);
+    SpmvTerm tm;
+    tm.vals = (const double *)(uintptr_t)rl64(desc, w0 + (int)(offsetof(SpmvTerm, vals) / 8));
+    tm.x.off = (int64_t)rl64(desc, w0 + (int)(offsetof(SpmvTerm, x) / 8));
+    tm.x.base = (int32_t)(unsigned)rl64(desc, w0 + (int)(offsetof(SpmvTerm, x) / 8) + 1);
+    tm.x.pad_ = 0;
+    return tm;
+}
+
 template <int R, int WFIX>
 __global__ __launch_bounds__(512) void pc_row_program(const RowOp *__restrict__ ops, int nphases,
                                                        const int2 *__restrict__ dep,
@@ -352,7 +469,10 @@ __global__ __launch_bounds__(512) void pc_row_program(const RowOp *__restrict__ 
     const int2 d = dep[j];
     const Bases B{{nullptr, nullptr, nullptr, nullptr}};
     bool dead = false;   // a spin timed out: stop waiting, run to the end, results invalid
+    unsigned long long dnext = load_desc_words(ops);
     for (int ph = 0; ph < nphases; ++ph) {
+        const unsigned long long desc = dnext;
+        if (ph + 1 < nphases) dnext = load_desc_words(ops + ph + 1);   // lands during this phase
         if (ph > 0) {
             if (wave == 0) {
                 const int jj = d.x + lane;
@@ -373,7 +493,9 @@ __global__ __launch_bounds__(512) void pc_row_program(const RowOp *__restrict__ 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __syncthreads();
         }
-        rowops_body<R, false, WFIX, true>(ops[ph], B, s);
+        const RowOp op = unpack_desc_head(desc);
+        rowops_body<R, false, WFIX, true>(
+            op, [&](int t) { return unpack_desc_term(desc, t); }, B, s);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0)
@@ -397,16 +519,6 @@ __global__ __launch_bounds__(512) void pc_row_program(const RowOp *__restrict__ 
 typedef KKT_GLOBAL unsigned long long *gu64_p;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// A phase descriptor (one RowOp, < 512 bytes) is fetched by ONE wave-wide vector load --
-// lane l holds bytes 8l..8l+7 -- a whole phase ahead, and its fields are moved to scalar
-// registers with v_readlane.  Reading the descriptor field by field through the scalar
-// cache cost a dependent ~1 us miss per touched line and phase (scripts/prog_stamps.py).
-static_assert(sizeof(RowOp) <= 512, "RowOp must fit one 64 x 8-byte wave load");
-__device__ __forceinline__ unsigned long long rl64(unsigned long long v, int lane) {
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
-    return ((unsigned long long)hi << 32) | lo;
-}
 #define KKT_D64(field) rl64(desc, (int)(offsetof(RowOp, field) / 8))
 #define KKT_DPTR(type, field) ((type)(uintptr_t)KKT_D64(field))
 #define KKT_DF64(field) __longlong_as_double((long long)KKT_D64(field))
