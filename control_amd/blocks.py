@@ -33,9 +33,36 @@ def _axpby(a, A, b, B):
     import numpy as np
     if (A.shape == B.shape and A.nnz == B.nnz and np.array_equal(A.indptr, B.indptr)
             and np.array_equal(A.indices, B.indices)):
-        return sp.csr_matrix((a * A.data + b * B.data, A.indices.copy(), A.indptr.copy()),
-                             shape=A.shape)
+        # index arrays are shared with A (blocks are never modified in place)
+        return sp.csr_matrix((a * A.data + b * B.data, A.indices, A.indptr), shape=A.shape)
     return _csr(a * A + b * B)
+
+
+_TRANSPOSE_PERM = {}
+
+
+def _transpose(A):
+    """``A^T`` as CSR.  For matrices with a symmetric sparsity structure (every FE matrix over
+    one connectivity) the transposed values are a fixed permutation of the values, cached per
+    structure: re-linearisation loops transpose hundreds of same-structure matrices."""
+    import numpy as np
+    A = _csr(A)
+    if A.shape[0] != A.shape[1]:
+        return _csr(A.T)
+    key = (A.shape, A.nnz, hash(A.indptr.tobytes()))
+    ent = _TRANSPOSE_PERM.get(key)
+    if ent is None:
+        T = _csr(sp.csr_matrix((np.arange(1, A.nnz + 1, dtype=np.float64), A.indices,
+                                A.indptr), shape=A.shape).T)
+        same = (T.nnz == A.nnz and np.array_equal(T.indptr, A.indptr)
+                and np.array_equal(T.indices, A.indices))
+        ent = (T.data.astype(np.int64) - 1) if same else False
+        if len(_TRANSPOSE_PERM) > 16:
+            _TRANSPOSE_PERM.clear()
+        _TRANSPOSE_PERM[key] = ent
+    if ent is False:
+        return _csr(A.T)
+    return sp.csr_matrix((A.data[ent], A.indices, A.indptr), shape=A.shape)
 
 
 def _own(A, share):
@@ -72,7 +99,7 @@ def instationary_blocks(M, K: Sequence, tau: float, beta: float, n_t: int,
         key = (a, id(K[i]), b, transpose)
         if share and key in cache:
             return cache[key]
-        Ki = _csr(K[i].T) if transpose else K[i]
+        Ki = _transpose(K[i]) if transpose else K[i]
         A = _axpby(a, Ki, b, M)
         cache[key] = A
         return A

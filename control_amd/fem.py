@@ -261,14 +261,35 @@ class TaylorHoodDiscretisation:
         convection term (``test/test_control.py:4194-4199``).  Same sparsity structure as
         ``M_v`` / ``K_v`` entry by entry, so it can be re-uploaded with
         ``kkt_update_block_values``."""
+        data = self.convection_v_data(w)
+        return sp.csr_matrix((data, self.K_v.indices.copy(), self.K_v.indptr.copy()),
+                             shape=self.K_v.shape)
+
+    def convection_v_data(self, w: np.ndarray) -> np.ndarray:
+        """The values of ``convection_v(w)`` on the structure of ``K_v`` (no sparse-matrix
+        construction: element entries are summed through a cached scatter map)."""
         e = self._need_elem()
         n2 = self.n_v // 2
         V = e["V"]
-        wq = np.stack([e["phi"] @ w[:n2][V].T, e["phi"] @ w[n2:][V].T], axis=2)  # (nq, ne, 2)
-        adv = np.einsum("qed,eqbd->eqb", wq, e["gphi"])                # (w . grad phi_b)
+        wq = np.stack([w[:n2][V] @ e["phi"].T, w[n2:][V] @ e["phi"].T], axis=2)  # (ne, nq, 2)
+        adv = np.matmul(e["gphi"], wq[..., None])[..., 0]              # (w . grad phi_b)
         Ne = np.einsum("eq,qa,eqb->eab", e["W"], e["phi"], adv)
-        N2 = _assemble_like(Ne, V, V, (n2, n2))
-        return _canonical_csr(sp.kron(sp.identity(2, format="csr"), N2))
+        if "scatter_v" not in e:
+            # CSR position of every element entry in the scalar P2 structure (one component)
+            K2 = self.K_v[:n2, :n2].tocsr()
+            K2.sort_indices()
+            rows = np.repeat(V, V.shape[1], axis=1).ravel()
+            cols = np.tile(V, (1, V.shape[1])).ravel()
+            key = K2.indptr[rows].astype(np.int64)
+            # position of `cols` inside each row's sorted index list
+            pos = np.empty(len(rows), dtype=np.int64)
+            for r0 in range(0, len(rows), 1 << 20):
+                sl = slice(r0, r0 + (1 << 20))
+                pos[sl] = [0] * 0 or _row_positions(K2, rows[sl], cols[sl])
+            e["scatter_v"] = key + pos
+            e["nnz2"] = K2.nnz
+        d2 = np.bincount(e["scatter_v"], weights=Ne.ravel(), minlength=e["nnz2"])
+        return np.concatenate([d2, d2])
 
     def convection_p(self, w: np.ndarray) -> sp.csr_matrix:
         """The same form on the pressure space (``construct_D_v(p_trial, p_test, ...)``,
@@ -289,6 +310,29 @@ class TaylorHoodDiscretisation:
     @property
     def n_p(self):
         return self.M_p.shape[0]
+
+
+def _row_positions(A, rows, cols):
+    """Index of ``cols[k]`` inside row ``rows[k]`` of the CSR matrix ``A`` (sorted indices)."""
+    out = np.empty(len(rows), dtype=np.int64)
+    # vectorised binary search per entry inside its row segment
+    lo = A.indptr[rows].astype(np.int64)
+    hi = A.indptr[rows + 1].astype(np.int64)
+    idx = A.indices
+    base = lo.copy()
+    n = (hi - lo).max()
+    step = 1
+    while step < n:
+        step <<= 1
+    pos = np.zeros(len(rows), dtype=np.int64)
+    while step:
+        cand = pos + step
+        ok = (cand < hi - base) & (idx[np.minimum(base + cand, len(idx) - 1)] <= cols)
+        pos = np.where(ok, cand, pos)
+        step >>= 1
+    out[:] = pos
+    assert np.array_equal(idx[base + pos], cols)
+    return out
 
 
 def _assemble_like(Ee, rows, cols, shape):
