@@ -111,6 +111,21 @@ __device__ __forceinline__ void load_cols(gci_p p, int (&c)[R]) {
     }
 }
 
+// Data-flow synchronisation of the persistent programs (see pc_row_program_g below): the
+// vector a phase produces also travels as {tag, 32 value bits} granules, two per row.
+struct NoGran {
+    static constexpr bool on = false;
+};
+struct Gran {
+    static constexpr bool on = true;
+    const unsigned long long *xg;   // granules written by the previous phase
+    unsigned long long *yg;         // granules this phase writes
+    unsigned ep_in, ep_out;         // tags to expect (0: gather plain memory) / to publish
+    unsigned *err;
+    bool dead;                      // a spin timed out: stop waiting, results invalid
+};
+constexpr unsigned GRAN_SPIN_LIMIT = 1u << 20;
+
 // `terms(t)` yields the t-th SpmvTerm of the op: from the descriptor in memory, or unpacked
 // from a wave-held copy (persistent programs), so that no descriptor array is indexed
 // dynamically in registers.
@@ -175,10 +190,10 @@ __device__ __forceinline__ void accumulate_exact(const RowOp &op, const TermFn &
     }
 }
 
-template <int R, bool NT, bool COH, class TermFn>
+template <int R, bool NT, bool COH, class TermFn, class GranT>
 __device__ __forceinline__ void accumulate_generic(const RowOp &op, const TermFn &terms,
                                                    const Bases &bases, size_t base, int w,
-                                                   double (&acc)[R]) {
+                                                   double (&acc)[R], GranT &gran) {
     constexpr int C = 64 * R;
     const gci_p colp = (gci_p)op.col + base;
     const int nterms = op.nterms;
@@ -188,7 +203,7 @@ __device__ __forceinline__ void accumulate_generic(const RowOp &op, const TermFn
         // once and the next chunk's indices travel with the current chunk's gathers; slots
         // past the slice width re-read the last valid slot with a zero value
         // (fma(0, x, acc) == acc), so there is no branch inside the chunk.
-        constexpr int KC = 12;
+        constexpr int KC = GranT::on ? 8 : 12;   // granule polls hold 4 registers per value
         for (int t = 0; t < (w > 0 ? nterms : 0); ++t) {
             const SpmvTerm tm = terms(t);
             const gcd_p vp = (gcd_p)tm.vals + base;
@@ -199,12 +214,56 @@ __device__ __forceinline__ void accumulate_generic(const RowOp &op, const TermFn
                 load_cols<R>(colp + (size_t)(k < w ? k : w - 1) * C, c[k]);
             for (int k0 = 0; k0 < w; k0 += KC) {
                 double v[KC][R], xv[KC][R];
+                bool plain = true;
+                if constexpr (GranT::on) plain = gran.ep_in == 0u;
 #pragma unroll
                 for (int k = 0; k < KC; ++k) {
                     const int kk = k0 + k < w ? k0 + k : w - 1;
                     load_vals<R, NT>(vp + (size_t)kk * C, v[k]);
+                }
+                if (plain) {
 #pragma unroll
-                    for (int q = 0; q < R; ++q) xv[k][q] = ldv<COH>(x + c[k][q]);
+                    for (int k = 0; k < KC; ++k)
+#pragma unroll
+                        for (int q = 0; q < R; ++q) xv[k][q] = ldv<COH>(x + c[k][q]);
+                }
+                if constexpr (GranT::on) {
+                    if (!plain) {
+                        // "the data is the flag": re-read the chunk's granules until every
+                        // tag carries the producing phase
+                        typedef KKT_GLOBAL const unsigned long long *gcu64_p;
+                        const gcu64_p xg = (gcu64_p)gran.xg;
+                        unsigned spins = 0;
+                        while (true) {
+                            unsigned long long ga[KC][R], gb[KC][R];
+#pragma unroll
+                            for (int k = 0; k < KC; ++k)
+#pragma unroll
+                                for (int q = 0; q < R; ++q) {
+                                    const gcu64_p g = xg + 2 * (size_t)c[k][q];
+                                    ga[k][q] = __hip_atomic_load(g, __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT);
+                                    gb[k][q] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                            bool ok = true;
+#pragma unroll
+                            for (int k = 0; k < KC; ++k)
+#pragma unroll
+                                for (int q = 0; q < R; ++q) {
+                                    ok &= (unsigned)(ga[k][q] >> 32) == gran.ep_in &&
+                                          (unsigned)(gb[k][q] >> 32) == gran.ep_in;
+                                    xv[k][q] = __longlong_as_double((long long)(
+                                        (ga[k][q] & 0xffffffffull) | (gb[k][q] << 32)));
+                                }
+                            if (__all(ok) || gran.dead) break;
+                            if (++spins >= GRAN_SPIN_LIMIT) {
+                                gran.dead = true;
+                                if ((threadIdx.x & 63) == 0) atomicOr(gran.err, 2u);
+                                break;
+                            }
+                        }
+                    }
                 }
                 if (k0 + KC < w) {
 #pragma unroll
@@ -241,9 +300,9 @@ __device__ __forceinline__ void accumulate_generic(const RowOp &op, const TermFn
 
 // WFIX > 0: the launcher knows every slice of every RowOp in the launch has width WFIX
 // (structured meshes: 7 for 2-D P1, 15 for 3-D P1) and picks the kernel unrolled for it.
-template <int R, bool NT, int WFIX, bool COH, class TermFn>
+template <int R, bool NT, int WFIX, bool COH, class TermFn, class GranT>
 __device__ __forceinline__ void rowops_body(const RowOp &op, const TermFn &terms,
-                                            const Bases &bases, const int s) {
+                                            const Bases &bases, const int s, GranT &gran) {
     const int lane = threadIdx.x & 63;
     if (s >= op.nslices) return;
     constexpr int C = 64 * R;
@@ -307,7 +366,7 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const TermFn &terms
         if constexpr (WFIX > 0)
             accumulate_exact<R, NT, WFIX, COH>(op, terms, bases, base, acc);
         else
-            accumulate_generic<R, NT, COH>(op, terms, bases, base, w, acc);
+            accumulate_generic<R, NT, COH>(op, terms, bases, base, w, acc, gran);
     }
 
     const gd_p y = (gd_p)resolve(op.y, bases);
@@ -344,12 +403,36 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const TermFn &terms
 #pragma unroll
     for (int q = 0; q < R; ++q)
         if (row[q] >= 0) stv<COH>(y + row[q], out[q]);
-    if (lin && op.y2.base >= 0) {
+    const bool has_y2 = lin && op.y2.base >= 0;
+    if (has_y2) {
         const gd_p y2 = (gd_p)resolve(op.y2, bases);
 #pragma unroll
         for (int q = 0; q < R; ++q)
             if (row[q] >= 0) stv<COH>(y2 + row[q], out2[q]);
     }
+    if constexpr (GranT::on) {
+        // the vector the next phase gathers (p_1 after a fused update, else y), as granules
+        typedef KKT_GLOBAL unsigned long long *gu64w_p;
+        const gu64w_p yg = (gu64w_p)gran.yg;
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+            if (row[q] >= 0) {
+                const unsigned long long bits =
+                    (unsigned long long)__double_as_longlong(has_y2 ? out2[q] : out[q]);
+                const unsigned long long tag = (unsigned long long)gran.ep_out << 32;
+                __hip_atomic_store(yg + 2 * (size_t)row[q], tag | (bits & 0xffffffffull),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(yg + 2 * (size_t)row[q] + 1, tag | (bits >> 32),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+    }
+}
+
+template <int R, bool NT, int WFIX, bool COH, class TermFn>
+__device__ __forceinline__ void rowops_body(const RowOp &op, const TermFn &terms,
+                                            const Bases &bases, const int s) {
+    NoGran none;
+    rowops_body<R, NT, WFIX, COH>(op, terms, bases, s, none);
 }
 
 // Two entry points over one body so that profiles separate the KKT operator apply (the
@@ -501,6 +584,36 @@ __global__ __launch_bounds__(512) void pc_row_program(const RowOp *__restrict__ 
         if (threadIdx.x == 0)
             __hip_atomic_store(flags + (size_t)j * FLAG_STRIDE, (unsigned)(ph + 1), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Data-flow form for structures without a small fixed width (P2 / Q2 / 3-D P1): the phases
+// of pc_row_program with the hand-off of pc_row_program_g -- gathers poll tagged granules in
+// chunks, outputs are published as granules, and there is no counter, no drain and no
+// workgroup barrier.  Matrix values and indices are re-read from L2 every phase (too wide to
+// keep in registers).  Needs the same symmetric gather relation between waves and the same
+// "phase ph gathers what phase ph - 1 produced" chain as pc_row_program_g.
+template <int R>
+__global__ __launch_bounds__(512) void pc_row_program_gw(const RowOp *__restrict__ ops, int nphases,
+                                                          unsigned long long *g0,
+                                                          unsigned long long *g1, unsigned *err) {
+    const int wave = threadIdx.x >> 6;
+    const int s = blockIdx.x * (blockDim.x >> 6) + wave;
+    const Bases B{{nullptr, nullptr, nullptr, nullptr}};
+    Gran gran;
+    gran.err = err;
+    gran.dead = false;
+    unsigned long long dnext = load_desc_words(ops);
+    for (int ph = 0; ph < nphases; ++ph) {
+        const unsigned long long desc = dnext;
+        if (ph + 1 < nphases) dnext = load_desc_words(ops + ph + 1);
+        const RowOp op = unpack_desc_head(desc);
+        gran.xg = (ph & 1) ? g0 : g1;
+        gran.yg = (ph & 1) ? g1 : g0;
+        gran.ep_in = (ph > 0 && op.nterms > 0) ? (unsigned)ph : 0u;
+        gran.ep_out = (unsigned)(ph + 1);
+        rowops_body<R, false, 0, true>(
+            op, [&](int t) { return unpack_desc_term(desc, t); }, B, s, gran);
     }
 }
 
@@ -866,6 +979,26 @@ void launch_row_program_g(hipStream_t s, const RowOp *d_ops, int nphases, int nw
     (void)hipMemsetAsync(g1, 0, granule_words * sizeof(unsigned long long), s);
     hipLaunchKernelGGL(pick_program_g(uniform_w), dim3(nwg), dim3(64 * waves_per_wg), 0, s, d_ops,
                        nphases, g0, g1, (unsigned)(granule_words * sizeof(unsigned long long)), d_err);
+}
+
+int row_program_gw_max_wgs(int waves_per_wg) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pc_row_program_gw<2>,
+                                                     64 * waves_per_wg, 0) != hipSuccess)
+        return 0;
+    if (per_cu > 4) per_cu = 4;
+    return cus * per_cu;
+}
+void launch_row_program_gw(hipStream_t s, const RowOp *d_ops, int nphases, int nwg,
+                           int waves_per_wg, unsigned long long *g0, unsigned long long *g1,
+                           size_t granule_words, unsigned *d_err) {
+    if (nphases <= 0 || nwg <= 0) return;
+    (void)hipMemsetAsync(g0, 0, granule_words * sizeof(unsigned long long), s);
+    (void)hipMemsetAsync(g1, 0, granule_words * sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(pc_row_program_gw<2>, dim3(nwg), dim3(64 * waves_per_wg), 0, s, d_ops,
+                       nphases, g0, g1, d_err);
 }
 
 int prog_flag_words(int nwg) { return nwg * FLAG_STRIDE; }

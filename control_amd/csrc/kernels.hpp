@@ -72,6 +72,11 @@ void launch_row_program_g(hipStream_t s, const RowOp *d_ops, int nphases, int nw
                           int uniform_w, unsigned long long *g0, unsigned long long *g1,
                           size_t granule_words, unsigned *d_err);
 int row_program_max_wgs(int R, int uniform_w, int waves_per_wg);
+// data-flow form for any width (R = 2): granule hand-off, matrix re-read from L2 every phase
+int row_program_gw_max_wgs(int waves_per_wg);
+void launch_row_program_gw(hipStream_t s, const RowOp *d_ops, int nphases, int nwg,
+                           int waves_per_wg, unsigned long long *g0, unsigned long long *g1,
+                           size_t granule_words, unsigned *d_err);
 void launch_row_program(hipStream_t s, const RowOp *d_ops, int nphases, int nwg, int waves_per_wg,
                         int R, int uniform_w, const int32_t *d_dep, unsigned *d_flags,
                         unsigned *d_err);

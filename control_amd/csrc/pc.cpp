@@ -115,7 +115,13 @@ void SchurPC::fuse_programs() {
     if (!d_dep_) {
         int wpw = 0, nwg = 0;
         const char *pm0 = std::getenv("KKT_PROG_MODE");
-        const bool try_g = !(pm0 && pm0[0] == 'f') && row_program_g_available(P.R, P.uniform_w);
+        const bool try_g0 = !(pm0 && pm0[0] == 'f') && row_program_g_available(P.R, P.uniform_w);
+        // the data-flow form for any width (matrix re-read from L2 every phase) is opt-in
+        // (KKT_PROG_MODE=w): re-polling whole chunks of granules costs more fabric traffic
+        // than the counter form's single gather round once rows are wide or row-sorted
+        // (measured: Stokes P2 47 -> 121 ms, 3-D P1 3.3 -> 4.8 ms per application)
+        const bool try_gw = pm0 && pm0[0] == 'w' && P.R == 2;
+        const bool try_g = !try_gw && try_g0;
         // data-flow form: one wave per workgroup (no workgroup barrier on the critical path)
         // while all of them are co-resident; else 4 / 8 waves per workgroup
         const char *pw = std::getenv("KKT_PROG_WAVES");
@@ -123,9 +129,9 @@ void SchurPC::fuse_programs() {
         for (int cand : {first, 4, 8}) {
             if (cand < 1 || cand > 8) continue;
             const int n = (P.nslices + cand - 1) / cand;
-            const int cap = try_g ? std::min(row_program_g_max_wgs(P.uniform_w, cand),
-                                             row_program_max_wgs(P.R, P.uniform_w, cand))
-                                  : row_program_max_wgs(P.R, P.uniform_w, cand);
+            int cap = row_program_max_wgs(P.R, P.uniform_w, cand);
+            if (try_g) cap = std::min(cap, row_program_g_max_wgs(P.uniform_w, cand));
+            if (try_gw) cap = std::min(cap, row_program_gw_max_wgs(cand));
             if (n <= cap) {
                 wpw = cand;
                 nwg = n;
@@ -176,24 +182,33 @@ void SchurPC::fuse_programs() {
         // data-flow form: needs the exact gather relation between workgroups to be symmetric
         {
             const char *pm = std::getenv("KKT_PROG_MODE");
-            bool want = !(pm && pm[0] == 'f') && row_program_g_available(P.R, P.uniform_w) &&
-                        nwg <= row_program_g_max_wgs(P.uniform_w, wpw);
+            const bool gw_ok = pm && pm[0] == 'w' && P.R == 2 &&
+                               nwg <= row_program_gw_max_wgs(wpw);
+            const bool g_ok = !gw_ok && row_program_g_available(P.R, P.uniform_w) &&
+                              nwg <= row_program_g_max_wgs(P.uniform_w, wpw);
+            bool want = !(pm && pm[0] == 'f') && (g_ok || gw_ok);
             if (want) {
-                std::vector<std::vector<int32_t>> reads(nwg);
-                for (int j = 0; j < nwg; ++j) {
-                    const int64_t r1 = std::min<int64_t>(P.nrows, (j + 1) * rpw);
-                    std::vector<char> seen(nwg, 0);
-                    for (int64_t r = j * rpw; r < r1; ++r)
+                // between waves (the unit that publishes and polls), in storage positions
+                const int64_t rw = 64 * P.R;
+                const int nw = P.nslices;
+                std::vector<std::vector<int32_t>> reads(nw);
+                for (int j = 0; j < nw; ++j) {
+                    std::vector<char> seen(nw, 0);
+                    for (int64_t p = j * rw; p < (j + 1) * rw; ++p) {
+                        const int64_t r = P.row_of(p);
+                        if (r < 0) continue;
                         for (int32_t q = P.h_indptr[r]; q < P.h_indptr[r + 1]; ++q)
-                            seen[P.h_indices[q] / rpw] = 1;
-                    for (int k = 0; k < nwg; ++k)
+                            seen[P.pos_of(P.h_indices[q]) / rw] = 1;
+                    }
+                    for (int k = 0; k < nw; ++k)
                         if (seen[k]) reads[j].push_back(k);
                 }
-                for (int j = 0; j < nwg && want; ++j)
+                for (int j = 0; j < nw && want; ++j)
                     for (int32_t k : reads[j])
                         if (!std::binary_search(reads[k].begin(), reads[k].end(), (int32_t)j))
                             want = false;
             }
+            prog_mode_ = want ? (g_ok ? 1 : 2) : 0;
             prog_granule_ = want;
             if (want) {
                 granule_words_ = 2 * (size_t)P.nslices * 64 * P.R;
@@ -243,6 +258,7 @@ void SchurPC::fuse_programs() {
             s.rows.d_ops = dev_upload(ops.data(), ops.size());
             s.nphases = (int)ops.size();
             s.granule = prog_granule_;
+            s.gmode = prog_mode_;
             out.push_back(s);
             k = e;
         } else {
@@ -792,7 +808,10 @@ void SchurPC::replay(size_t first, size_t last) {
                 break;
             case PcStep::PROG: {
                 const Pattern &P = S_.patterns[m_pat_];
-                if (s.granule)
+                if (s.gmode == 2)
+                    launch_row_program_gw(st, s.rows.d_ops, s.nphases, prog_nwg_, prog_wpw_, d_g0_,
+                                          d_g1_, granule_words_, d_err_);
+                else if (s.granule)
                     launch_row_program_g(st, s.rows.d_ops, s.nphases, prog_nwg_, prog_wpw_,
                                          P.uniform_w, d_g0_, d_g1_, granule_words_, d_err_);
                 else

@@ -23,6 +23,7 @@ struct PcStep {
     int dst = -1, src = -1;         // COMM: send x to dst, receive y from src
     int nphases = 0;                // PROG: rows.d_ops holds nphases single-block RowOps
     bool granule = false;           // PROG: data-flow form (tagged granules)
+    int gmode = 0;                  // PROG: 0 counters, 1 data-flow fixed width, 2 data-flow any width
 };
 
 // A device-resident pc_fn: reads the nullspace-corrected right-hand side from in(), leaves
@@ -101,6 +102,7 @@ class SchurPC : public PcBase {
     int32_t *d_dep_ = nullptr;
     unsigned *d_flags_ = nullptr, *d_err_ = nullptr;
     bool prog_granule_ = false;
+    int prog_mode_ = 0;   // 0 counter form, 1 pc_row_program_g, 2 pc_row_program_gw
     unsigned long long *d_g0_ = nullptr, *d_g1_ = nullptr;
     size_t granule_words_ = 0;
     void fuse_programs();

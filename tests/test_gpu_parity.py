@@ -68,7 +68,8 @@ def test_preconditioner_parity_many_workgroups(CN):
     assert common.rel_err(got, ref) < 1e-10
     # same arithmetic in the same order: plain launches, the counter form and the data-flow
     # form of the persistent program agree exactly
-    for var, val in (("KKT_PERSISTENT", "0"), ("KKT_PROG_MODE", "flags")):
+    # ("w": the opt-in data-flow form for any row width, matrix re-read every phase)
+    for var, val in (("KKT_PERSISTENT", "0"), ("KKT_PROG_MODE", "flags"), ("KKT_PROG_MODE", "w")):
         os.environ[var] = val
         try:
             other = common.gpu_system(p).pc_apply(x, common.gpu_pc(p, MASS, schur))
