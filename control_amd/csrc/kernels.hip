@@ -652,8 +652,9 @@ __device__ __forceinline__ gcd_p vref_ptr(long long off, int base) {
 // their pointer changes.  What remains on the critical path of a Chebyshev phase is the
 // descriptor fetch and ONE gather round trip.
 template <int R, int W>
-__global__ __launch_bounds__(512) void pc_row_program_g(const RowOp *__restrict__ ops, int nphases,
-                                                         unsigned long long *g0,
+__global__ __launch_bounds__(512) void pc_row_program_g(const RowOp *__restrict__ ops,
+                                                         const PhaseLite *__restrict__ lite,
+                                                         int nphases, unsigned long long *g0,
                                                          unsigned long long *g1, unsigned gbytes,
                                                          unsigned *err) {
     constexpr int C = 64 * R;
@@ -720,13 +721,55 @@ __global__ __launch_bounds__(512) void pc_row_program_g(const RowOp *__restrict_
     };
     unsigned long long dnext = load_desc(0);
     bool dead = false;   // a spin timed out: stop waiting, run to the end, results invalid
+    // state that a STEP phase (PhaseLite, kind 1) inherits from the last fully decoded phase
+    int op_nslices = 0, nrows = 0;
+    PhaseLite lnext = lite[0];
     for (int ph = 0; ph < nphases; ++ph) {
         const unsigned long long desc = dnext;
-        if (ph + 1 < nphases) dnext = load_desc(ph + 1);   // in flight during this phase
-        const int op_nslices = KKT_D32(nslices);
-        const int nrows = KKT_D32(nrows);
-        const int op_nterms = KKT_D32(nterms);
-        const bool lin = KKT_D32(mode) == EPI_LIN;
+        const PhaseLite L = lnext;
+        if (ph + 1 < nphases) {
+            dnext = load_desc(ph + 1);   // in flight during this phase
+            lnext = lite[ph + 1];        // 64 bytes through the scalar cache, one phase ahead
+        }
+        // A STEP phase is a Chebyshev step of the solve the previous phase belongs to: same
+        // matrix, diagonal, right-hand side and mask; p_k is what the previous phase produced
+        // and p_{k-1} what the phase before it produced.  Everything it needs beyond the 64-byte
+        // record is already in registers -- no descriptor decoding, no pointer compares.
+        const bool step = L.kind == 1u;
+        int op_nterms;
+        bool lin;
+        gcd_p p_y, p_y2, pa, pb, pc, pd;
+        const void *d_col = cols_ptr, *d_vals0 = vals_ptr;
+        double k_ca = 0.0, k_cy = 0.0, k_cz = 0.0, k_malpha = 0.0;
+        double k_c1, k_c2, k_c3, k_post1, k_post2;
+        double e0[R], e1[R], e2[R], e3[R];
+        if (step) {
+            op_nterms = 1;
+            lin = false;
+            p_y = (gcd_p)(const double *)(uintptr_t)L.y;
+            p_y2 = nullptr;
+            pa = (L.flags & 1u) ? (gcd_p)(const double *)kp2 : nullptr;
+            pb = (gcd_p)(const double *)kp0;
+            pc = (gcd_p)(const double *)kp3;
+            pd = (gcd_p)(const double *)kp4;
+            k_c1 = L.c1;
+            k_c2 = L.c2;
+            k_c3 = L.c3;
+            k_post1 = L.post1;
+            k_post2 = L.post2;
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                e0[q] = kv2[q];
+                e1[q] = kv0[q];
+                e2[q] = kv3[q];
+                e3[q] = kv4[q];
+            }
+        } else {
+            op_nslices = KKT_D32(nslices);
+            nrows = KKT_D32(nrows);
+            op_nterms = KKT_D32(nterms);
+            lin = KKT_D32(mode) == EPI_LIN;
+        }
         const bool active = s < op_nslices;
         const int nterms = active ? op_nterms : 0;
         KKT_STAGE(0);   // descriptor
@@ -735,51 +778,51 @@ __global__ __launch_bounds__(512) void pc_row_program_g(const RowOp *__restrict_
             (void *)((ph & 1) ? g1 : g0), 0, (int)gbytes, 0x00020000);
         const unsigned ep_in = (ph > 0 && op_nterms > 0) ? (unsigned)ph : 0u;
         const unsigned ep_out = (unsigned)(ph + 1);
-        // program descriptors carry absolute pointers only (base 0) or null (base < 0)
-        const gcd_p p_y = vref_ptr((long long)KKT_D64(y.off), KKT_D32(y.base));
-        const gcd_p p_y2 = vref_ptr((long long)KKT_D64(y2.off), KKT_D32(y2.base));
-        const void *d_rowmask = KKT_DPTR(const void *, rowmask);
-        const void *d_col = KKT_DPTR(const void *, col);
-        const void *d_vals0 = KKT_DPTR(const void *, t[0].vals);
-        const gcd_p d_dinv = (gcd_p)KKT_DPTR(const double *, dinv);
+        if (!step) {
+            // program descriptors carry absolute pointers only (base 0) or null (base < 0)
+            p_y = vref_ptr((long long)KKT_D64(y.off), KKT_D32(y.base));
+            p_y2 = vref_ptr((long long)KKT_D64(y2.off), KKT_D32(y2.base));
+            const void *d_rowmask = KKT_DPTR(const void *, rowmask);
+            d_col = KKT_DPTR(const void *, col);
+            d_vals0 = KKT_DPTR(const void *, t[0].vals);
+            const gcd_p d_dinv = (gcd_p)KKT_DPTR(const double *, dinv);
 
-        // ---- operands of this thread's own rows (cache first)
-        gcd_p pa, pb, pc, pd;
-        if (lin) {
-            pa = vref_ptr((long long)KKT_D64(yin.off), KKT_D32(yin.base));
-            pb = vref_ptr((long long)KKT_D64(z.off), KKT_D32(z.base));
-            pc = vref_ptr((long long)KKT_D64(mx.off), KKT_D32(mx.base));
-            pd = p_y2 ? d_dinv : nullptr;
-        } else {
-            pa = vref_ptr((long long)KKT_D64(pkm1.off), KKT_D32(pkm1.base));
-            pb = vref_ptr((long long)KKT_D64(pk.off), KKT_D32(pk.base));
-            pc = vref_ptr((long long)KKT_D64(b.off), KKT_D32(b.base));
-            pd = d_dinv;
-        }
-        if (d_rowmask != mask_ptr) {
-            mask_ptr = d_rowmask;
-            const gcb_p rowmask = (gcb_p)(const uint8_t *)d_rowmask;
-#pragma unroll
-            for (int q = 0; q < R; ++q) {
-                const int r = r0 + 64 * q;
-                masked[q] = active && r < nrows && rowmask != nullptr && rowmask[r] != 0;
+            // ---- operands of this thread's own rows (cache first)
+            if (lin) {
+                pa = vref_ptr((long long)KKT_D64(yin.off), KKT_D32(yin.base));
+                pb = vref_ptr((long long)KKT_D64(z.off), KKT_D32(z.base));
+                pc = vref_ptr((long long)KKT_D64(mx.off), KKT_D32(mx.base));
+                pd = p_y2 ? d_dinv : nullptr;
+            } else {
+                pa = vref_ptr((long long)KKT_D64(pkm1.off), KKT_D32(pkm1.base));
+                pb = vref_ptr((long long)KKT_D64(pk.off), KKT_D32(pk.base));
+                pc = vref_ptr((long long)KKT_D64(b.off), KKT_D32(b.base));
+                pd = d_dinv;
             }
-        }
-        double e0[R], e1[R], e2[R], e3[R];
-        KKT_FETCH(e0, pa);
-        KKT_FETCH(e1, pb);
-        KKT_FETCH(e2, pc);
-        KKT_FETCH(e3, pd);
-        // b (Chebyshev) and dinv stay the same through a solve: pin them
-        if (!lin) {
-            kp3 = (const void *)(const double *)pc;
+            if (d_rowmask != mask_ptr) {
+                mask_ptr = d_rowmask;
+                const gcb_p rowmask = (gcb_p)(const uint8_t *)d_rowmask;
 #pragma unroll
-            for (int q = 0; q < R; ++q) kv3[q] = e2[q];
-        }
-        if (pd) {
-            kp4 = (const void *)(const double *)pd;
+                for (int q = 0; q < R; ++q) {
+                    const int r = r0 + 64 * q;
+                    masked[q] = active && r < nrows && rowmask != nullptr && rowmask[r] != 0;
+                }
+            }
+            KKT_FETCH(e0, pa);
+            KKT_FETCH(e1, pb);
+            KKT_FETCH(e2, pc);
+            KKT_FETCH(e3, pd);
+            // b (Chebyshev) and dinv stay the same through a solve: pin them
+            if (!lin) {
+                kp3 = (const void *)(const double *)pc;
 #pragma unroll
-            for (int q = 0; q < R; ++q) kv4[q] = e3[q];
+                for (int q = 0; q < R; ++q) kv3[q] = e2[q];
+            }
+            if (pd) {
+                kp4 = (const void *)(const double *)pd;
+#pragma unroll
+                for (int q = 0; q < R; ++q) kv4[q] = e3[q];
+            }
         }
 
         KKT_STAGE(1);   // own-row operands (cache or memory)
@@ -877,9 +920,17 @@ __global__ __launch_bounds__(512) void pc_row_program_g(const RowOp *__restrict_
 
         const gd_p y = (gd_p)p_y;
         const gd_p y2 = lin ? (gd_p)p_y2 : nullptr;
-        const double k_ca = KKT_DF64(ca), k_cy = KKT_DF64(cy), k_cz = KKT_DF64(cz);
-        const double k_malpha = KKT_DF64(malpha), k_c1 = KKT_DF64(c1), k_c2 = KKT_DF64(c2);
-        const double k_c3 = KKT_DF64(c3), k_post1 = KKT_DF64(post1), k_post2 = KKT_DF64(post2);
+        if (!step) {   // decoded after the gather: these moves overlap the poll's round trip
+            k_ca = KKT_DF64(ca);
+            k_cy = KKT_DF64(cy);
+            k_cz = KKT_DF64(cz);
+            k_malpha = KKT_DF64(malpha);
+            k_c1 = KKT_DF64(c1);
+            k_c2 = KKT_DF64(c2);
+            k_c3 = KKT_DF64(c3);
+            k_post1 = KKT_DF64(post1);
+            k_post2 = KKT_DF64(post2);
+        }
         double outv[R], out2v[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) {
@@ -949,8 +1000,8 @@ __global__ __launch_bounds__(512) void pc_row_program_g(const RowOp *__restrict_
 #undef KKT_STAGE
 }
 
-typedef void (*progg_fn)(const RowOp *, int, unsigned long long *, unsigned long long *, unsigned,
-                         unsigned *);
+typedef void (*progg_fn)(const RowOp *, const PhaseLite *, int, unsigned long long *,
+                         unsigned long long *, unsigned, unsigned *);
 static progg_fn pick_program_g(int uniform_w) {
     switch (uniform_w) {
 #define KKT_W(n) case n: return pc_row_program_g<2, n>;
@@ -970,15 +1021,16 @@ int row_program_g_max_wgs(int uniform_w, int waves_per_wg) {
     if (per_cu > 4) per_cu = 4;
     return cus * per_cu;
 }
-void launch_row_program_g(hipStream_t s, const RowOp *d_ops, int nphases, int nwg, int waves_per_wg,
-                          int uniform_w, unsigned long long *g0, unsigned long long *g1,
-                          size_t granule_words, unsigned *d_err) {
+void launch_row_program_g(hipStream_t s, const RowOp *d_ops, const PhaseLite *d_lite, int nphases,
+                          int nwg, int waves_per_wg, int uniform_w, unsigned long long *g0,
+                          unsigned long long *g1, size_t granule_words, unsigned *d_err) {
     if (nphases <= 0 || nwg <= 0) return;
     // tags of an earlier launch must not match this launch's epochs
     (void)hipMemsetAsync(g0, 0, granule_words * sizeof(unsigned long long), s);
     (void)hipMemsetAsync(g1, 0, granule_words * sizeof(unsigned long long), s);
     hipLaunchKernelGGL(pick_program_g(uniform_w), dim3(nwg), dim3(64 * waves_per_wg), 0, s, d_ops,
-                       nphases, g0, g1, (unsigned)(granule_words * sizeof(unsigned long long)), d_err);
+                       d_lite, nphases, g0, g1,
+                       (unsigned)(granule_words * sizeof(unsigned long long)), d_err);
 }
 
 int row_program_gw_max_wgs(int waves_per_wg) {

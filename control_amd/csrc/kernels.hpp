@@ -68,9 +68,19 @@ int prog_flag_words(int nwg);
 // data-flow form (tagged granules instead of phase counters), uniform widths 1..16 only
 bool row_program_g_available(int R, int uniform_w);
 int row_program_g_max_wgs(int uniform_w, int waves_per_wg);
-void launch_row_program_g(hipStream_t s, const RowOp *d_ops, int nphases, int nwg, int waves_per_wg,
-                          int uniform_w, unsigned long long *g0, unsigned long long *g1,
-                          size_t granule_words, unsigned *d_err);
+// Compact record of a phase, read through the scalar cache one phase ahead.  kind 1 (STEP): a
+// Chebyshev step that inherits matrix, diagonal, right-hand side and mask from the previous
+// phase, with p_k = the previous phase's output and p_{k-1} (flags bit 0) the one before.
+struct PhaseLite {
+    uint32_t kind, flags;
+    uint64_t y;
+    double c1, c2, c3, post1, post2;
+    uint64_t pad_;
+};
+static_assert(sizeof(PhaseLite) == 64, "one scalar cache line");
+void launch_row_program_g(hipStream_t s, const RowOp *d_ops, const PhaseLite *d_lite, int nphases,
+                          int nwg, int waves_per_wg, int uniform_w, unsigned long long *g0,
+                          unsigned long long *g1, size_t granule_words, unsigned *d_err);
 int row_program_max_wgs(int R, int uniform_w, int waves_per_wg);
 // data-flow form for any width (R = 2): granule hand-off, matrix re-read from L2 every phase
 int row_program_gw_max_wgs(int waves_per_wg);

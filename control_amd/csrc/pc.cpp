@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 
 namespace kkt {
@@ -68,6 +69,8 @@ void SchurPC::clear_program() {
     for (auto &s : steps_)
         if ((s.kind == PcStep::ROWS || s.kind == PcStep::PROG) && s.rows.d_ops)
             (void)hipFree(s.rows.d_ops);
+    for (auto &s : steps_)
+        if (s.d_lite) (void)hipFree(s.d_lite);
     steps_.clear();
     n_events_ = 0;
     cur_lane_ = 0;
@@ -220,6 +223,10 @@ void SchurPC::fuse_programs() {
         }
         prog_wpw_ = wpw;
         prog_nwg_ = nwg;
+        if (std::getenv("KKT_VERBOSE"))
+            std::fprintf(stderr, "[kkt] sweep program: mode %d (0 counters, 1 data-flow, 2 data-flow "
+                         "any width), %d workgroups x %d waves, %d slices\n",
+                         prog_mode_, nwg, wpw, P.nslices);
         d_dep_ = dev_upload(dep.data(), dep.size());
         d_flags_ = dev_alloc<unsigned>(prog_flag_words(nwg));
         d_err_ = dev_alloc<unsigned>(64 + 16 * 1024);   // word 0: error bits; rest: debug stamps
@@ -257,6 +264,48 @@ void SchurPC::fuse_programs() {
             s.kind = PcStep::PROG;
             s.rows.d_ops = dev_upload(ops.data(), ops.size());
             s.nphases = (int)ops.size();
+            {
+                // compact records: Chebyshev steps that only continue the previous phase's
+                // solve are marked STEP (kernels.hpp, PhaseLite)
+                std::vector<PhaseLite> lite(ops.size());
+                static const bool use_steps = [] {
+                    const char *e = std::getenv("KKT_PROG_STEPS");
+                    return !(e && e[0] == '0');
+                }();
+                auto same = [](const VRef &a, const VRef &b) {
+                    return a.base == b.base && (a.base < 0 || a.off == b.off);
+                };
+                for (size_t e2 = 0; e2 < ops.size(); ++e2) {
+                    const RowOp &op = ops[e2];
+                    PhaseLite L{};
+                    L.kind = 0;
+                    if (use_steps && e2 >= 1) {
+                        const RowOp &pv = ops[e2 - 1];
+                        const bool has_pkm1 = op.pkm1.base >= 0;
+                        bool stepk = op.mode == EPI_CHEB && pv.mode == EPI_CHEB &&
+                                     op.nterms == 1 && pv.nterms == 1 &&
+                                     op.t[0].vals == pv.t[0].vals && op.col == pv.col &&
+                                     op.rowmask == pv.rowmask && op.dinv == pv.dinv &&
+                                     op.nslices == pv.nslices && op.nrows == pv.nrows &&
+                                     same(op.b, pv.b) && op.b.base == 0 && op.y.base == 0 &&
+                                     op.pk.base == 0 && same(op.pk, pv.y) &&
+                                     same(op.t[0].x, pv.y) &&
+                                     (!has_pkm1 || (pv.pk.base == 0 && same(op.pkm1, pv.pk)));
+                        if (stepk) {
+                            L.kind = 1;
+                            L.flags = has_pkm1 ? 1u : 0u;
+                            L.y = (uint64_t)op.y.off;
+                            L.c1 = op.c1;
+                            L.c2 = op.c2;
+                            L.c3 = op.c3;
+                            L.post1 = op.post1;
+                            L.post2 = op.post2;
+                        }
+                    }
+                    lite[e2] = L;
+                }
+                s.d_lite = dev_upload(lite.data(), lite.size());
+            }
             s.granule = prog_granule_;
             s.gmode = prog_mode_;
             out.push_back(s);
@@ -812,7 +861,7 @@ void SchurPC::replay(size_t first, size_t last) {
                     launch_row_program_gw(st, s.rows.d_ops, s.nphases, prog_nwg_, prog_wpw_, d_g0_,
                                           d_g1_, granule_words_, d_err_);
                 else if (s.granule)
-                    launch_row_program_g(st, s.rows.d_ops, s.nphases, prog_nwg_, prog_wpw_,
+                    launch_row_program_g(st, s.rows.d_ops, s.d_lite, s.nphases, prog_nwg_, prog_wpw_,
                                          P.uniform_w, d_g0_, d_g1_, granule_words_, d_err_);
                 else
                     launch_row_program(st, s.rows.d_ops, s.nphases, prog_nwg_, prog_wpw_, P.R,

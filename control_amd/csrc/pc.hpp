@@ -23,6 +23,7 @@ struct PcStep {
     int dst = -1, src = -1;         // COMM: send x to dst, receive y from src
     int nphases = 0;                // PROG: rows.d_ops holds nphases single-block RowOps
     bool granule = false;           // PROG: data-flow form (tagged granules)
+    PhaseLite *d_lite = nullptr;    // PROG: compact per-phase records (data-flow form)
     int gmode = 0;                  // PROG: 0 counters, 1 data-flow fixed width, 2 data-flow any width
 };
 
