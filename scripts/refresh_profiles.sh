@@ -12,4 +12,9 @@ echo "heat profile done"
 timeout -k 10 300 python bench.py --workload stokes2d --steps 20 --warmup 3 > $o/bench_stokes2d.json 2> $o/stokes.err
 KKT_NO_GRAPH=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $o/stokes -o s --output-format csv -- python3 bench.py --workload stokes2d --steps 5 --warmup 1 > $o/stokes_under_rocprof.json 2> $o/stokes_prof.err
 echo "stokes profile done"
+: > $o/other_configs.jsonl
+for extra in "--scheme CN" "--mode S" "--workload heat3d --n 32 --n_t 32"; do
+  timeout -k 10 300 python bench.py --no-cpu-baseline $extra >> $o/other_configs.jsonl 2>> $o/other.err
+done
+cut -c88-108 $o/other_configs.jsonl
 ls -R $o | head -30
