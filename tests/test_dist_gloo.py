@@ -116,3 +116,47 @@ def test_two_rank_sharded_algorithm_matches_single_rank(CN):
         assert abs(d["its"][0] - d["its"][1]) <= (0 if CN else 1), d
         assert d["e_u"] < (1e-6 if CN else 1e-5), d
     assert covered == list(range(len(covered)))
+
+
+def _transport_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, os.path.dirname(HERE))
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        from control_amd.dist import GlooTransport
+        tr = GlooTransport(rank, world)
+        a = np.arange(5, dtype=np.float64) + 10.0 * rank
+        s = a.copy()
+        tr.allreduce(s, 0)
+        mx = a.copy()
+        tr.allreduce(mx, 1)
+        # ring: everybody sends its rank to the next rank and receives from the previous one
+        dst = rank + 1 if rank + 1 < world else -1
+        src = rank - 1 if rank > 0 else -1
+        got = tr.sendrecv(np.full(3, float(rank)), dst, 3 if src >= 0 else 0, src)
+        q.put((rank, s.tolist(), mx.tolist(), None if got is None else got.tolist()))
+    except Exception:          # pragma: no cover
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), None))
+
+
+def test_gloo_rehearsal_transport():
+    """``control_amd.dist.GlooTransport`` (the host-staged transport `bench.py` uses with
+    ``KKT_TRANSPORT=gloo`` to rehearse N > 1 on one GPU): sum / max all-reduce and the
+    neighbour hand-off, three ranks."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    world, port, q = 3, _free_port(), None
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_transport_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    base = np.arange(5, dtype=np.float64)
+    for rank, s, mx, got in out:
+        assert s != "error", mx
+        assert s == (3 * base + 30.0).tolist()
+        assert mx == (base + 20.0).tolist()
+        assert got == (None if rank == 0 else [float(rank - 1)] * 3)
