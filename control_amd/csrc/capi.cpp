@@ -105,6 +105,7 @@ int kkt_set_pc_schur(kkt_handle h, const kkt_pc_desc *desc) {
         S.pc.reset();
         S.pc_cb = nullptr;
         S.pc.reset(new SchurPC(S, *desc));
+        S.pc_stale = false;
     });
 }
 

@@ -89,6 +89,10 @@ void System::ns_pc_post(double *y, const double *u, const double *b) {
 void System::pc_apply(const double *d_x, double *d_y) {
     if (!finalized) fail(KKT_ERR_STATE, "system not finalized");
     info.last_pc_applies++;
+    if (pc && pc_stale) {
+        pc->values_changed();
+        pc_stale = false;
+    }
     double *in, *out;
     if (pc) {
         in = pc->in();

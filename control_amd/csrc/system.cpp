@@ -592,7 +592,9 @@ void System::update_block_values(int q, int i, int j, const double *vals) {
         launch_mask_columns(stream, va.d_vals, P.d_col, bc_sets[va.colmask_set].d_mask, P.npadded);
     HIPCHK(hipStreamSynchronize(stream));
     HIPCHK(hipFree(d_csr));
-    if (pc) pc->values_changed();
+    // the preconditioner's matrices are sums with block values: rebuilt lazily, once, at the
+    // next application (a Picard iteration updates hundreds of blocks in a row)
+    pc_stale = true;
 }
 
 // y = A x  (preconditioner.py:375-543)

@@ -167,6 +167,7 @@ struct System {
 
     // preconditioner
     std::unique_ptr<PcBase> pc;
+    bool pc_stale = false;   // block values changed since the preconditioner was built
     kkt_pc_callback pc_cb = nullptr;
     void *pc_cb_user = nullptr;
     bool pc_cb_failed = false;

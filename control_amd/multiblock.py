@@ -240,7 +240,8 @@ class MultiBlockSystem:
                 ncols = nx0 if q in (Q00, Q10) else nx1
                 # the same Python object given for several (i, j) shares device storage
                 sid = share_ids.setdefault(id(A), len(share_ids))
-                self._structure[(q, i, j)] = (len(data), hash(indices.tobytes()))
+                # the index array is kept referenced, so its address identifies it for good
+                self._structure[(q, i, j)] = (len(data), hash(indices.tobytes()), indices)
                 self._ck(self._lib.kkt_add_block(
                     self._h, q, i, j, nrows, ncols,
                     indptr.ctypes.data_as(_lib.c_i32p), indices.ctypes.data_as(_lib.c_i32p),
@@ -293,7 +294,11 @@ class MultiBlockSystem:
     def update_block_values(self, quadrant, i, j, A):
         """New values on a stored block's structure (Picard re-linearisation)."""
         _, indices, data = _as_csr(A)
-        if self._structure.get((quadrant, i, j)) != (len(data), hash(indices.tobytes())):
+        ref = self._structure.get((quadrant, i, j))
+        # same index buffer as at construction (block sums share it): nothing to compare
+        same = ref is not None and ref[0] == len(data) and (
+            ref[2].ctypes.data == indices.ctypes.data or ref[1] == hash(indices.tobytes()))
+        if not same:
             raise ValueError(f"block ({quadrant}; {i}, {j}): the new matrix does not have the "
                              "stored sparsity structure")
         self._ck(self._lib.kkt_update_block_values(
