@@ -225,3 +225,64 @@ def test_instationary_picard_loop_on_the_gpu(CN):
     assert len(out[0][0]) == len(out[1][0])
     assert np.abs(out[0][1] - out[1][1]).max() < 1e-9
     assert np.abs(out[0][2] - out[1][2]).max() < 1e-9
+
+
+def _mms_poisson_control(N):
+    """``test/test_control.py:122-230``: stationary Poisson control, P1 on
+    ``UnitSquareMesh(N, N)``, beta = 1e-3, manufactured state and adjoint."""
+    from control_amd.control import Stationary
+    from control_amd.fem import unit_square_p1
+    disc = unit_square_p1(N)
+    beta = 1.0e-3
+
+    def ref_v(X):
+        return np.sin(np.pi * X[:, 0]) * np.sin(np.pi * X[:, 1]) * np.exp(X[:, 0] + X[:, 1])
+
+    def ref_zeta(X):
+        return np.sin(2 * np.pi * X[:, 0]) * np.sin(2 * np.pi * X[:, 1])
+
+    def lapl_v(X):      # div(grad(sin(pi x) sin(pi y) exp(x + y)))
+        x, y = X[:, 0], X[:, 1]
+        sx, cx, sy, cy = np.sin(np.pi * x), np.cos(np.pi * x), np.sin(np.pi * y), np.cos(np.pi * y)
+        e = np.exp(x + y)
+        return e * (2.0 * (1.0 - np.pi**2) * sx * sy + 2.0 * np.pi * (cx * sy + sx * cy))
+
+    def v_d(X):         # -lapl(zeta) + v
+        return 8.0 * np.pi**2 * ref_zeta(X) + ref_v(X)
+
+    def f(X):           # -lapl(v) - zeta / beta
+        return -lapl_v(X) - ref_zeta(X) / beta
+    return Stationary(disc, desired_state=v_d, force_f=f, beta=beta), disc, ref_v, ref_zeta
+
+
+MMS_POISSON_SP = {"linear_solver": "fgmres", "fgmres_restart": 10, "maximum_iterations": 500,
+                  "relative_tolerance": 1.0e-6, "absolute_tolerance": 1.0e-6,
+                  "monitor_convergence": False}
+
+
+def test_mms_stationary_poisson_control_orders():
+    """Second order in h for state and adjoint (the reference prints the orders)."""
+    errs = []
+    for N in (8, 16, 32):
+        ctl, disc, ref_v, ref_zeta = _mms_poisson_control(N)
+        ksp = ctl.linear_solve(solver_parameters=MMS_POISSON_SP, lambda_v_bounds=(0.5, 2.0),
+                               backend=common.OracleBackend(schur=(40, 0.01, 2.2)))
+        assert ksp.reason > 0
+        dv, dz = ctl._v - ref_v(disc.coords), ctl._zeta - ref_zeta(disc.coords)
+        errs.append((np.sqrt(dv @ (disc.M @ dv)), np.sqrt(dz @ (disc.M @ dz))))
+    errs = np.array(errs)
+    orders = np.log(errs[:-1] / errs[1:]) / np.log(2.0)
+    # 8 -> 16 is pre-asymptotic (1.67 / 1.78 measured), 16 -> 32 gives 1.91 / 1.95
+    assert orders[0].min() > 1.6 and orders[1].min() > 1.9, (errs, orders)
+
+
+@pytest.mark.gpu
+def test_mms_stationary_poisson_control_on_the_gpu():
+    from control_amd.control import GpuBackend
+    ctl, disc, ref_v, ref_zeta = _mms_poisson_control(32)
+    ksp = ctl.linear_solve(solver_parameters=MMS_POISSON_SP, lambda_v_bounds=(0.5, 2.0),
+                           backend=GpuBackend(schur=(40, 0.01, 2.2)))
+    assert ksp.getConvergedReason() > 0
+    dv, dz = ctl._v - ref_v(disc.coords), ctl._zeta - ref_zeta(disc.coords)
+    # discretisation errors at N = 32 (oracle backend: 6.2e-2 / 4.4e-3)
+    assert np.sqrt(dv @ (disc.M @ dv)) < 8e-2 and np.sqrt(dz @ (disc.M @ dz)) < 6e-3
