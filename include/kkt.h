@@ -95,7 +95,9 @@ int kkt_add_block(kkt_handle h, int quadrant, int i, int j,
                   const int32_t *indptr, const int32_t *indices,
                   const double *values, int64_t share_id);
 /* New values on the stored structure of a block (re-linearisation in a Picard loop,
- * control.py:3377-3590); valid after kkt_finalize. */
+ * control.py:3377-3590); valid after kkt_finalize.  A built-in preconditioner whose matrices
+ * are sums with block values is marked stale and rebuilt once, on the device, at its next
+ * application -- not per updated block. */
 int kkt_update_block_values(kkt_handle h, int quadrant, int i, int j,
                             const double *values);
 
