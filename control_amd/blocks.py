@@ -17,7 +17,8 @@ from typing import Sequence
 
 import scipy.sparse as sp
 
-__all__ = ["instationary_blocks", "stationary_blocks", "instationary_incompressible_blocks"]
+__all__ = ["instationary_blocks", "stationary_blocks", "instationary_incompressible_blocks",
+           "stationary_incompressible_blocks"]
 
 
 def _csr(A):
@@ -75,6 +76,20 @@ def stationary_blocks(M, K, beta):
     K = _csr(K)
     return ({(0, 0): M}, {(0, 0): _csr(K.T)}, {(0, 0): K},
             {(0, 0): _csr((-1.0 / beta) * M)})
+
+
+def stationary_incompressible_blocks(M_v, D_v, B, beta):
+    """Outer block system of ``Stationary.incompressible_linear_solve``
+    (``control/control.py:896-919``): velocity-space blocks (v, zeta), pressure-space blocks
+    (mu, p)."""
+    M_v, D_v, B = _csr(M_v), _csr(D_v), _csr(B)
+    B_T = _csr(B.T)
+    b00 = {(0, 0): M_v, (0, 1): _transpose(D_v), (1, 0): D_v,
+           (1, 1): _csr((-1.0 / beta) * M_v)}
+    b01 = {(0, 0): B_T, (0, 1): None, (1, 0): None, (1, 1): B_T}
+    b10 = {(0, 0): B, (0, 1): None, (1, 0): None, (1, 1): B}
+    b11 = {(0, 0): None, (0, 1): None, (1, 0): None, (1, 1): None}
+    return b00, b01, b10, b11
 
 
 def instationary_blocks(M, K: Sequence, tau: float, beta: float, n_t: int,

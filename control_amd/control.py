@@ -19,7 +19,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from .blocks import (instationary_blocks, instationary_incompressible_blocks,
-                     stationary_blocks)
+                     stationary_blocks, stationary_incompressible_blocks)
 
 __all__ = ["Instationary", "Stationary", "GpuBackend"]
 
@@ -61,6 +61,22 @@ class GpuBackend:
                            M_p=th.M_p, kp=mb.ChebSpec(*self.kp),
                            mp=mb.ChebSpec(20, *lambda_p_bounds), n_p_blocks=m, b_scale=tau,
                            post_scale=1.0 / tau**2, cn=CN)
+
+
+    def construct_stokes_pc_stationary(self, th, D_v, D_p, beta, lambda_v_bounds,
+                                       lambda_p_bounds):
+        """``pc_fn`` of ``control.py:986-1085`` as a ``StokesPC`` descriptor."""
+        mb = self._mb
+        nsv = (mb.DirichletBCNullspace(th.boundary_v),)
+        i00, i01, i10, i11 = stationary_blocks(th.M_v, D_v, beta)
+        inner = self.MultiBlockSystem(th.n_v, th.n_v, i00, i01, i10, i11, nullspace_0=nsv,
+                                      nullspace_1=nsv)
+        comm = self.MultiBlockSystem(th.n_p, th.n_p, *stationary_blocks(th.M_p, D_p, beta))
+        inner_pc = self.construct_pc("stationary", th.M_v, i01, i10, 1, 0.0, beta,
+                                     th.boundary_v, lambda_v_bounds, 0.0)
+        return mb.StokesPC(inner=inner, inner_pc=inner_pc, commutator=comm, B=th.B, K_p=th.K_p,
+                           M_p=th.M_p, kp=mb.ChebSpec(*self.kp),
+                           mp=mb.ChebSpec(20, *lambda_p_bounds))
 
 
 def _apply_T_1(b):            # preconditioner.py:33-45
@@ -461,6 +477,9 @@ class Stationary:
 
     def __init__(self, disc, forward_operator=None, *, desired_state=None, force_f=None,
                  beta=1.0e-3, bcs_v=None, forward_jacobian=None):
+        self._th = disc if hasattr(disc, "M_v") else None
+        if self._th is not None:
+            disc = _VelocitySpace(disc)
         self._disc = disc
         self._forward = forward_operator or (lambda v: disc.K)
         self._jacobian = forward_jacobian
@@ -486,7 +505,10 @@ class Stationary:
     def _v_inhom(self):
         v = np.zeros(self._disc.n_dofs)
         if self._bcs_v is not None:
-            v[self._disc.boundary] = self._bcs_v(self._disc.coords[self._disc.boundary])
+            Xb = getattr(self._disc, "bc_coords", None)
+            if Xb is None:
+                Xb = self._disc.coords[self._disc.boundary]
+            v[self._disc.boundary] = self._bcs_v(Xb)
         return v
 
     def set_v(self, v):                      # control.py:264-272
@@ -580,3 +602,59 @@ class Stationary:
             if k + 1 > max_non_linear_iter:
                 break
         return norms
+
+    def incompressible_linear_solve(self, nullspace_p=None, *, forward_operator_p=None, P=None,
+                                    solver_parameters=None, lambda_v_bounds=None,
+                                    lambda_p_bounds=None, v_d=None, f=None, div_v=None,
+                                    div_zeta=None, print_error=False, backend=None):
+        """``control.py:802-1110``: stationary Stokes-type control.  Fields afterwards: ``_v``,
+        ``_zeta`` (velocity space, component-major), ``_p``, ``_mu``."""
+        backend = backend or GpuBackend()
+        th = self._th
+        if th is None:
+            raise ValueError("Undefined space_p")                    # control.py:813-817
+        disc, beta, nodes = self._disc, self._beta, self._disc.boundary
+        M = disc.M
+        inhom = self._bcs_v is not None
+        D_v = self.construct_D_v(self._v)
+        D_p = sp.csr_matrix(forward_operator_p(self._v) if forward_operator_p else th.K_p)
+        v_inhom = self._v_inhom()
+        if f is None or v_d is None:
+            v_d_data, f_data = self._data()
+        if f is None:
+            f = f_data - (D_v @ v_inhom if inhom else 0.0)
+            if inhom:
+                f[nodes] = 0.0
+        if v_d is None:
+            v_d = v_d_data - (M @ v_inhom if inhom else 0.0)
+            if inhom:
+                v_d[nodes] = 0.0
+        if div_v is None:                                            # :866-871
+            div_v = -(th.B @ v_inhom) if inhom else np.zeros(th.n_p)
+        if div_zeta is None:
+            div_zeta = np.zeros(th.n_p)
+        b_0 = np.stack([v_d, f])
+        b_1 = np.stack([div_v, div_zeta])
+        blocks = stationary_incompressible_blocks(th.M_v, D_v, th.B, beta)
+        if P is None:
+            pc_fn = backend.construct_stokes_pc_stationary(
+                th, D_v, D_p, beta, lambda_v_bounds or (0.3924, 2.0598),
+                lambda_p_bounds or (0.5, 2.0))
+        else:
+            pc_fn = P
+        if solver_parameters is None:                                # :921-927
+            solver_parameters = {"linear_solver": "fgmres", "fgmres_restart": 10,
+                                 "maximum_iterations": 100, "relative_tolerance": 1.0e-6,
+                                 "absolute_tolerance": 0.0, "monitor_convergence": print_error}
+        nsv = tuple(backend.DirichletBCNullspace(nodes) for _ in range(2))
+        nsp = tuple((nullspace_p.__class__() if nullspace_p is not None
+                     else backend.ConstantNullspace()) for _ in range(2))
+        system = backend.MultiBlockSystem(th.n_v, th.n_p, *blocks, n_blocks_00=2, n_blocks_11=2,
+                                          nullspace_0=nsv, nullspace_1=nsp)
+        u_0 = np.zeros((2, th.n_v))
+        u_1 = np.zeros((2, th.n_p))
+        ksp = system.solve(u_0, u_1, b_0, b_1, solver_parameters=solver_parameters, pc_fn=pc_fn)
+        self.set_v(u_0[0] + (v_inhom if inhom else 0.0))            # :1092-1100
+        self.set_zeta(u_0[1])
+        self._mu, self._p = u_1[0].copy(), u_1[1].copy()
+        return ksp

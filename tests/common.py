@@ -295,3 +295,15 @@ def stokes_exact_sol_control(CN, n=8, n_t=20):
                        initial_condition=lambda X: true_v(X, 0.0), time_interval=(0.0, T_f),
                        CN=CN, n_t=n_t, bcs_v=lambda Xb, t: true_v(Xb, t))
     return ctl, th, true_v
+
+
+def _oracle_backend_stokes_pc_stationary(self, th, D_v, D_p, beta, lambda_v_bounds,
+                                         lambda_p_bounds):
+    ko = self._ko
+    return ko.pc_stationary_incompressible(
+        th.M_v, D_v, th.B, th.M_p, th.K_p, D_p, beta, th.boundary_v,
+        ko.ChebSpec(20, *lambda_v_bounds), ko.ChebSpec(*self.schur), ko.ChebSpec(*self.schur),
+        ko.ChebSpec(20, *lambda_p_bounds))
+
+
+OracleBackend.construct_stokes_pc_stationary = _oracle_backend_stokes_pc_stationary

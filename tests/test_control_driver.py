@@ -286,3 +286,93 @@ def test_mms_stationary_poisson_control_on_the_gpu():
     dv, dz = ctl._v - ref_v(disc.coords), ctl._zeta - ref_zeta(disc.coords)
     # discretisation errors at N = 32 (oracle backend: 6.2e-2 / 4.4e-3)
     assert np.sqrt(dv @ (disc.M @ dv)) < 8e-2 and np.sqrt(dz @ (disc.M @ dz)) < 6e-3
+
+
+# ------------------------------------------------ Stationary.incompressible_linear_solve
+
+def _mms_stokes_control(N):
+    """``test/test_control.py:361-553``: stationary Stokes control, P2-P1 on
+    ``RectangleMesh(N, N, 2, 2)``, beta = 1e-3, exact (v, p, zeta, mu), inhomogeneous Dirichlet
+    data v = v_exact on the boundary."""
+    from control_amd.control import Stationary
+    from control_amd.fem import rectangle_p2p1
+    th = rectangle_p2p1(N, N, 2.0, 2.0)
+    beta = 1.0e-3
+
+    def XY(P):
+        return P[:, 0] - 1.0, P[:, 1] - 1.0
+
+    def v_ex(P):
+        x, y = XY(P)
+        return np.concatenate([x * y**3, 0.25 * (x**4 - y**4)])
+
+    def p_ex(P):
+        x, y = XY(P)
+        return 3.0 * x**2 * y - y**3
+
+    def zeta_ex(P):
+        x, y = XY(P)
+        return np.concatenate([beta * 2.0 * y * (x**2 - 1.0)**2 * (y**2 - 1.0),
+                               -beta * 2.0 * x * (x**2 - 1.0) * (y**2 - 1.0)**2])
+
+    def mu_ex(P):
+        x, y = XY(P)
+        return beta * 4.0 * x * y
+
+    def v_d(P):        # -lapl(zeta) + grad(mu) + v
+        x, y = XY(P)
+        lz1 = 2.0 * beta * (y * (y**2 - 1.0) * (12.0 * x**2 - 4.0) + 6.0 * y * (x**2 - 1.0)**2)
+        lz2 = -2.0 * beta * (6.0 * x * (y**2 - 1.0)**2 + x * (x**2 - 1.0) * (12.0 * y**2 - 4.0))
+        return np.concatenate([-lz1 + 4.0 * beta * y, -lz2 + 4.0 * beta * x]) + v_ex(P)
+
+    def f(P):          # -lapl(v) + grad(p) - zeta / beta, and -lapl(v) + grad(p) = 0
+        return -zeta_ex(P) / beta
+    ctl = Stationary(th, desired_state=v_d, force_f=f, beta=beta, bcs_v=v_ex)
+    return ctl, th, v_ex, p_ex, zeta_ex, mu_ex
+
+
+MMS_STOKES_SP = {"linear_solver": "fgmres", "fgmres_restart": 10, "maximum_iterations": 200,
+                 "relative_tolerance": 1.0e-10, "absolute_tolerance": 1.0e-10,
+                 "monitor_convergence": False}
+
+
+def _stokes_errors(ctl, th, v_ex, p_ex, zeta_ex, mu_ex):
+    def l2(M, e):
+        return np.sqrt(abs(e @ (M @ e)))
+
+    def demean(M, q):
+        return q - (np.ones_like(q) @ (M @ q)) / (np.ones_like(q) @ (M @ np.ones_like(q)))
+    return (l2(th.M_v, ctl._v - v_ex(th.coords_v)), l2(th.M_v, ctl._zeta - zeta_ex(th.coords_v)),
+            l2(th.M_p, demean(th.M_p, ctl._p) - demean(th.M_p, p_ex(th.coords_p))),
+            l2(th.M_p, demean(th.M_p, ctl._mu) - demean(th.M_p, mu_ex(th.coords_p))))
+
+
+def test_mms_stationary_stokes_control_orders():
+    """Third order for the P2 velocities, second for the P1 pressures (the reference prints
+    the orders); exercises the lifting of inhomogeneous Dirichlet data in all three rows."""
+    errs = []
+    for N in (4, 8, 16):
+        ctl, th, *ex = _mms_stokes_control(N)
+        ksp = ctl.incompressible_linear_solve(
+            solver_parameters=MMS_STOKES_SP, lambda_v_bounds=(0.3924, 2.0598),
+            lambda_p_bounds=(0.5, 2.0), backend=common.OracleBackend(schur=(40, 0.01, 2.25)))
+        assert ksp.reason > 0
+        errs.append(_stokes_errors(ctl, th, *ex))
+    errs = np.array(errs)
+    orders = np.log(errs[:-1] / errs[1:]) / np.log(2.0)
+    assert orders[:, :2].min() > 2.6 and orders[:, 2:].min() > 1.7, (errs, orders)
+
+
+@pytest.mark.gpu
+def test_mms_stationary_stokes_control_on_the_gpu():
+    from control_amd.control import GpuBackend
+    ctl, th, *ex = _mms_stokes_control(8)
+    ksp = ctl.incompressible_linear_solve(
+        solver_parameters=MMS_STOKES_SP, lambda_v_bounds=(0.3924, 2.0598),
+        lambda_p_bounds=(0.5, 2.0), backend=GpuBackend(schur=(40, 0.01, 2.25)))
+    assert ksp.getConvergedReason() > 0
+    ref, *_ = _mms_stokes_control(8)
+    ref.incompressible_linear_solve(
+        solver_parameters=MMS_STOKES_SP, lambda_v_bounds=(0.3924, 2.0598),
+        lambda_p_bounds=(0.5, 2.0), backend=common.OracleBackend(schur=(40, 0.01, 2.25)))
+    assert np.abs(ctl._v - ref._v).max() < 1e-7 and np.abs(ctl._zeta - ref._zeta).max() < 1e-8
