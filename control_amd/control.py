@@ -521,7 +521,8 @@ class Stationary:
 
     def _data(self):
         M, X = self._disc.M, self._disc.coords
-        f = (M @ self._force_f(X)) if self._force_f is not None else np.zeros(len(X))
+        f = ((M @ self._force_f(X)) if self._force_f is not None
+             else np.zeros(self._disc.n_dofs))
         return M @ self._desired_state(X), f
 
     def linear_solve(self, *, P=None, solver_parameters=None, lambda_v_bounds=None, v_d=None,
@@ -658,3 +659,60 @@ class Stationary:
         self.set_zeta(u_0[1])
         self._mu, self._p = u_1[0].copy(), u_1[1].copy()
         return ksp
+
+    def incompressible_non_linear_solve(self, nullspace_p=None, *, forward_operator_p=None,
+                                        P=None, solver_parameters=None, lambda_v_bounds=None,
+                                        lambda_p_bounds=None, max_non_linear_iter=10,
+                                        relative_non_linear_tol=1.0e-5,
+                                        absolute_non_linear_tol=1.0e-8,
+                                        print_error_non_linear=False, backend=None):
+        """``control.py:1112-1480``: Picard loop of stationary Navier-Stokes-type control around
+        ``incompressible_linear_solve``; returns the residual norms (initial one first)."""
+        th = self._th
+        if th is None:
+            raise ValueError("Undefined space_p")
+        disc, beta, nodes = self._disc, self._beta, self._disc.boundary
+        M, B = disc.M, th.B
+        BT = sp.csr_matrix(B.T)
+        v_old, zeta_old = self._v.copy(), self._zeta.copy()
+        p_old = getattr(self, "_p", np.zeros(th.n_p)).copy()
+        mu_old = getattr(self, "_mu", np.zeros(th.n_p)).copy()
+        v_d, f = self._data()
+
+        def evaluate():                                              # :1272-1310
+            D_v = self.construct_D_v(v_old)
+            r00 = v_d - M @ v_old - D_v.T @ zeta_old - BT @ mu_old
+            r01 = f - D_v @ v_old + (1.0 / beta) * (M @ zeta_old) - BT @ p_old
+            r00[nodes] = 0.0
+            r01[nodes] = 0.0
+            r10, r11 = -(B @ v_old), -(B @ zeta_old)
+            n = np.sqrt(r00 @ r00 + r01 @ r01 + r10 @ r10 + r11 @ r11)
+            return r00, r01, r10, r11, float(n)
+        r00, r01, r10, r11, norm_0 = evaluate()
+        norm_k, k, norms = norm_0, 0, [norm_0]
+        while norm_k > relative_non_linear_tol * norm_0 and norm_k > absolute_non_linear_tol:
+            self._v = v_old          # linearisation point (control.py:839-840)
+            self.incompressible_linear_solve(
+                nullspace_p, forward_operator_p=forward_operator_p, P=P,
+                solver_parameters=solver_parameters, lambda_v_bounds=lambda_v_bounds,
+                lambda_p_bounds=lambda_p_bounds, v_d=r00, f=r01, div_v=r10, div_zeta=r11,
+                backend=backend)
+            v_old = v_old + self._v
+            if self._bcs_v is not None:
+                v_old[nodes] = self._v_inhom()[nodes]
+            zeta_old = zeta_old + self._zeta
+            zeta_old[nodes] = 0.0
+            p_old = p_old + self._p
+            mu_old = mu_old + self._mu
+            self.set_v(v_old)
+            self.set_zeta(zeta_old)
+            self._p, self._mu = p_old.copy(), mu_old.copy()
+            r00, r01, r10, r11, norm_k = evaluate()
+            norms.append(norm_k)
+            k += 1
+            if print_error_non_linear:
+                print(f"Non-linear solver: iteration {k:d}, non-linear residual norm "
+                      f"{norm_k:.16e}")
+            if k + 1 > max_non_linear_iter:
+                break
+        return norms

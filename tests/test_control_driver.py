@@ -376,3 +376,51 @@ def test_mms_stationary_stokes_control_on_the_gpu():
         solver_parameters=MMS_STOKES_SP, lambda_v_bounds=(0.3924, 2.0598),
         lambda_p_bounds=(0.5, 2.0), backend=common.OracleBackend(schur=(40, 0.01, 2.25)))
     assert np.abs(ctl._v - ref._v).max() < 1e-7 and np.abs(ctl._zeta - ref._zeta).max() < 1e-8
+
+
+def _stationary_navier_stokes_control(N=4, nu=1.0):
+    """Shaped like ``test/test_control.py:1027-1092``: stationary Navier-Stokes control on
+    P2-P1, ``forward_form = nu grad-grad + (w . grad)``, homogeneous velocity conditions."""
+    from control_amd.control import Stationary
+    from control_amd.fem import rectangle_p2p1
+    th = rectangle_p2p1(N, N, 2.0, 2.0)
+
+    def v_d(X):
+        return np.concatenate([np.sin(0.5 * np.pi * X[:, 0]) ** 2 * np.sin(np.pi * X[:, 1]),
+                               -np.sin(np.pi * X[:, 0]) * np.sin(0.5 * np.pi * X[:, 1]) ** 2])
+
+    def D_v(w):
+        return nu * th.K_v + th.convection_v(w)
+
+    def D_p(w):
+        return nu * th.K_p + th.convection_p(w)
+    return Stationary(th, D_v, desired_state=v_d, beta=1.0e-2), th, D_p
+
+
+def test_stationary_navier_stokes_picard_with_the_oracle():
+    ctl, th, D_p = _stationary_navier_stokes_control()
+    norms = ctl.incompressible_non_linear_solve(
+        forward_operator_p=D_p, solver_parameters=MMS_STOKES_SP,
+        lambda_v_bounds=(0.3924, 2.0598), lambda_p_bounds=(0.5, 2.0), max_non_linear_iter=20,
+        relative_non_linear_tol=1.0e-8, absolute_non_linear_tol=0.0,
+        backend=common.OracleBackend(schur=(40, 0.01, 2.25)))
+    assert norms[-1] <= 1.0e-8 * norms[0]
+    assert all(b < a for a, b in zip(norms[1:], norms[2:]))
+    assert np.abs(th.B @ ctl._v).max() < 1e-8          # discretely divergence-free state
+
+
+@pytest.mark.gpu
+def test_stationary_navier_stokes_picard_on_the_gpu():
+    from control_amd.control import GpuBackend
+    out = []
+    for be in (GpuBackend(schur=(40, 0.01, 2.25)), common.OracleBackend(schur=(40, 0.01, 2.25))):
+        ctl, th, D_p = _stationary_navier_stokes_control()
+        norms = ctl.incompressible_non_linear_solve(
+            forward_operator_p=D_p, solver_parameters=MMS_STOKES_SP,
+            lambda_v_bounds=(0.3924, 2.0598), lambda_p_bounds=(0.5, 2.0),
+            max_non_linear_iter=20, relative_non_linear_tol=1.0e-8, absolute_non_linear_tol=0.0,
+            backend=be)
+        out.append((norms, ctl._v.copy(), ctl._zeta.copy()))
+    assert len(out[0][0]) == len(out[1][0])
+    assert np.abs(out[0][1] - out[1][1]).max() < 1e-7
+    assert np.abs(out[0][2] - out[1][2]).max() < 1e-8
