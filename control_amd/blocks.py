@@ -18,7 +18,7 @@ from typing import Sequence
 import scipy.sparse as sp
 
 __all__ = ["instationary_blocks", "stationary_blocks", "instationary_incompressible_blocks",
-           "stationary_incompressible_blocks"]
+           "stationary_incompressible_blocks", "conform_to"]
 
 
 def _csr(A):
@@ -37,6 +37,44 @@ def _axpby(a, A, b, B):
         # index arrays are shared with A (blocks are never modified in place)
         return sp.csr_matrix((a * A.data + b * B.data, A.indices, A.indptr), shape=A.shape)
     return _csr(a * A + b * B)
+
+
+def conform_to(A, like):
+    """``A`` on the sparsity structure of ``like`` (explicit zeros where ``A`` has no entry).
+    SciPy arithmetic drops entries that cancel or are zero, so a forward operator built as
+    ``nu * K + N`` usually has fewer stored entries than the mass matrix; the block-Schur
+    preconditioner forms ``D + c M`` entry by entry and needs one structure for both.
+    Raises if ``A`` has an entry outside the structure of ``like``."""
+    import numpy as np
+    A, like = _csr(A), _csr(like)
+    if A.shape != like.shape:
+        raise ValueError("conform_to: shapes differ")
+    if (A.nnz == like.nnz and np.array_equal(A.indptr, like.indptr)
+            and np.array_equal(A.indices, like.indices)):
+        return A
+    rows = np.repeat(np.arange(A.shape[0]), np.diff(A.indptr))
+    # position of every entry of A inside the row of `like` it belongs to
+    key_like = like.indptr[:-1].astype(np.int64)
+    lo = key_like[rows]
+    hi = like.indptr[1:].astype(np.int64)[rows]
+    pos = lo.copy()
+    width = int(np.diff(like.indptr).max()) if like.nnz else 0
+    step = 1
+    while step < max(width, 1):
+        step <<= 1
+    off = np.zeros(len(rows), dtype=np.int64)
+    idx = like.indices
+    while step:
+        cand = off + step
+        ok = (lo + cand < hi) & (idx[np.minimum(lo + cand, len(idx) - 1)] <= A.indices)
+        off = np.where(ok, cand, off)
+        step >>= 1
+    pos = lo + off
+    if len(rows) and not np.array_equal(idx[pos], A.indices):
+        raise ValueError("conform_to: the matrix has entries outside the target structure")
+    data = np.zeros(like.nnz)
+    data[pos] = A.data
+    return sp.csr_matrix((data, like.indices, like.indptr), shape=like.shape)
 
 
 _TRANSPOSE_PERM = {}

@@ -18,7 +18,7 @@ from __future__ import annotations
 import numpy as np
 import scipy.sparse as sp
 
-from .blocks import (instationary_blocks, instationary_incompressible_blocks,
+from .blocks import (conform_to, instationary_blocks, instationary_incompressible_blocks,
                      stationary_blocks, stationary_incompressible_blocks)
 
 __all__ = ["Instationary", "Stationary", "GpuBackend"]
@@ -257,9 +257,9 @@ class Instationary:
         if check_v_d:
             v_d = self.construct_v_d()
         v_old = self._v
-        D = [sp.csr_matrix(self._forward(v_old[i], t_0 + i * tau)) for i in range(n_t)]
+        D = [conform_to(self._forward(v_old[i], t_0 + i * tau), M) for i in range(n_t)]
         b00, b01, b10, b11, m = instationary_blocks(M, D, tau, beta, n_t, CN)
-        D_0 = sp.csr_matrix(self._forward(v_0, t_0))
+        D_0 = conform_to(self._forward(v_0, t_0), M)
 
         b_0, b_1 = self._velocity_rows(D, D_0, v_0, v_d, f, check_v_d, check_f)
         if CN:
@@ -407,9 +407,9 @@ class Instationary:
         if check_v_d:
             v_d = self.construct_v_d()
         v_old = self._v
-        D = [sp.csr_matrix(self._forward(v_old[i], t_0 + i * tau)) for i in range(n_t)]
-        Dp = [sp.csr_matrix(fwd_p(v_old[i], t_0 + i * tau)) for i in range(n_t)]
-        D_0 = sp.csr_matrix(self._forward(v_0, t_0))
+        D = [conform_to(self._forward(v_old[i], t_0 + i * tau), th.M_v) for i in range(n_t)]
+        Dp = [conform_to(fwd_p(v_old[i], t_0 + i * tau), th.M_p) for i in range(n_t)]
+        D_0 = conform_to(self._forward(v_0, t_0), th.M_v)
         bl = instationary_incompressible_blocks(th.M_v, D, th.B, th.M_p, Dp, tau, beta, n_t, CN)
         m = bl["m"]
         b_0_0, b_0_1 = self._velocity_rows(D, D_0, v_0, v_d, f, check_v_d, check_f)
@@ -499,8 +499,9 @@ class Stationary:
         self._Gauss_Newton = False
 
     def construct_D_v(self, v_old):          # control.py:310-320
-        return sp.csr_matrix(self._jacobian(v_old) if self._Gauss_Newton
-                             else self._forward(v_old))
+        # on the mass matrix's structure: the preconditioner adds multiples of M entry by entry
+        return conform_to(self._jacobian(v_old) if self._Gauss_Newton
+                          else self._forward(v_old), self._disc.M)
 
     def _v_inhom(self):
         v = np.zeros(self._disc.n_dofs)
@@ -618,7 +619,7 @@ class Stationary:
         M = disc.M
         inhom = self._bcs_v is not None
         D_v = self.construct_D_v(self._v)
-        D_p = sp.csr_matrix(forward_operator_p(self._v) if forward_operator_p else th.K_p)
+        D_p = conform_to(forward_operator_p(self._v) if forward_operator_p else th.K_p, th.M_p)
         v_inhom = self._v_inhom()
         if f is None or v_d is None:
             v_d_data, f_data = self._data()
