@@ -195,8 +195,8 @@ def bench_stokes(args, world):
                                 f"beta={beta:g}, T={args.T:g}, {args.scheme}, mode {args.mode}"),
                    "unknowns": int(n_local), "n_v": int(th.n_v), "n_p": int(th.n_p),
                    "krylov": "outer fgmres restart 10; inner gmres, 5 iterations per application",
-                   "pc_apply_ms": pc_ms, "kkt_apply_ms": spmv_ms,
-            "time_to_solution": tts},
+                   "preconditioner": f"StokesPC, Chebyshev (its, emin, emax): {specs}",
+                   "pc_apply_ms": pc_ms, "kkt_apply_ms": spmv_ms},
         "roofline": {"kernel": "kkt_spmv_rows (outer Stokes-control operator)", "bound": "hbm",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
