@@ -12,5 +12,5 @@ for extra in "--scheme CN" "--mode S" "--workload heat3d --n 32 --n_t 32" "--sch
   timeout -k 10 300 python bench.py --no-cpu-baseline $extra >> $o/other_configs.jsonl 2>> $o/other.err
 done
 cut -c88-108 $o/other_configs.jsonl
-KKT_TRANSPORT=gloo KKT_DEVICE=0 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 5 > $o/bench_n2_gloo.json 2> $o/bench_n2_gloo.err || { tail -5 $o/bench_n2_gloo.err; exit 1; }
+KKT_PERSISTENT=0 KKT_TRANSPORT=gloo KKT_DEVICE=0 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 5 > $o/bench_n2_gloo.json 2> $o/bench_n2_gloo.err || { tail -5 $o/bench_n2_gloo.err; exit 1; }
 cut -c88-108 $o/bench_n2_gloo.json
