@@ -307,38 +307,49 @@ def main():
     its, dt = run(args.steps)
     assert its == args.steps, (its, args.steps)
 
-    tts = None
-    if not p["CN"]:   # (the CN rows differ; the headline configuration is BE)
-        # ---- time to solution: the README right-hand side (v_d = t c, f = c), library-default
-        # stopping test (gmres, restart 10, rtol 1e-6, control.py:3261-3266), at most 300 iterations
-        sd, m, tau = p["sd"], p["m"], p["tau"]
-        X = sd.coords
-        cX = np.prod(np.cos(0.5 * np.pi * (X - 1.0)), axis=1)
-        lo = getattr(gsys, "_lo", 0)
-        nloc = info["n_local"] // (2 * sd.n_dofs)
-        lv = range(lo, lo + nloc)                       # levels this rank owns (BE: block = level)
-        off = 0
-        r0 = np.stack([tau * (sd.M @ ((i + off) * tau * cX)) * (i < p["n_t"] - 1) for i in lv])
-        r1 = np.stack([tau * (sd.M @ cX) * (i + off >= 1) for i in lv])
-        r0[:, p["nodes"]] = 0.0
-        r1[:, p["nodes"]] = 0.0
-        d_rhs = dvec(np.concatenate([r0.ravel(), r1.ravel()]))
-        gsys._ck(lib.kkt_vec_upload(h, d_u, _lib.f64(np.zeros(n_local))[1]))
-        gsys._ck(lib.kkt_set_krylov(h, 0, -1, 10, 1.0e-6, 0.0, -1.0, 300))
-        s_its, s_reason, s_nh, s_rn = C.c_int(), C.c_int(), C.c_int(), C.c_double()
-        gsys._ck(lib.kkt_comm_barrier(h))
-        gsys._ck(lib.kkt_sync(h))
-        t0 = time.perf_counter()
-        gsys._ck(lib.kkt_solve_device(h, d_rhs, d_u, C.byref(s_its), C.byref(s_reason),
-                                      C.byref(s_rn), None, 0, C.byref(s_nh)))
-        gsys._ck(lib.kkt_sync(h))
-        gsys._ck(lib.kkt_comm_barrier(h))
-        s_dt = C.c_double(time.perf_counter() - t0)
-        gsys._ck(lib.kkt_comm_max(h, C.byref(s_dt)))
-        tts = {"rhs": "README example (v_d = t c, f = c), zero initial guess",
-               "stopping_test": "gmres restart 10, rtol 1e-6 (library default), max 300",
-               "converged": bool(s_reason.value > 0), "iterations": int(s_its.value),
-               "seconds": s_dt.value}
+    # ---- time to solution: the README right-hand side (v_d = t c, f = c, zero initial state),
+    # rows as control.py:2991-3243, library-default stopping test (gmres, restart 10,
+    # rtol 1e-6, control.py:3261-3266), at most 300 iterations
+    sd, m, tau, n_t = p["sd"], p["m"], p["tau"], p["n_t"]
+    X = sd.coords
+    cX = np.prod(np.cos(0.5 * np.pi * (X - 1.0)), axis=1)
+    Mc = sd.M @ cX
+    vd = np.stack([(i * tau) * Mc for i in range(n_t)])       # assemble(inner(v_d, test) dx)
+    ff = np.stack([Mc for _ in range(n_t)])
+    if p["CN"]:
+        h2 = 0.5 * tau
+        g0 = np.stack([h2 * (vd[i] + vd[i + 1]) for i in range(m)])
+        g1 = np.stack([h2 * (ff[i] + ff[i + 1]) for i in range(m)])
+    else:
+        g0 = np.stack([tau * vd[i] * (i < n_t - 1) for i in range(m)])
+        g1 = np.stack([tau * ff[i] * (i >= 1) for i in range(m)])
+    g0[:, p["nodes"]] = 0.0
+    g1[:, p["nodes"]] = 0.0
+    if p["CN"]:                                              # apply_T_1 / apply_T_2, :3242
+        t0_, t1_ = g0.copy(), g1.copy()
+        t0_[:-1] += g0[1:]
+        t1_[1:] += g1[:-1]
+        g0, g1 = t0_, t1_
+    lo = getattr(gsys, "_lo", 0)
+    nloc = info["n_local"] // (2 * sd.n_dofs)
+    r0, r1 = g0[lo:lo + nloc], g1[lo:lo + nloc]
+    d_rhs = dvec(np.concatenate([r0.ravel(), r1.ravel()]))
+    gsys._ck(lib.kkt_vec_upload(h, d_u, _lib.f64(np.zeros(n_local))[1]))
+    gsys._ck(lib.kkt_set_krylov(h, 0, -1, 10, 1.0e-6, 0.0, -1.0, 300))
+    s_its, s_reason, s_nh, s_rn = C.c_int(), C.c_int(), C.c_int(), C.c_double()
+    gsys._ck(lib.kkt_comm_barrier(h))
+    gsys._ck(lib.kkt_sync(h))
+    t0 = time.perf_counter()
+    gsys._ck(lib.kkt_solve_device(h, d_rhs, d_u, C.byref(s_its), C.byref(s_reason),
+                                  C.byref(s_rn), None, 0, C.byref(s_nh)))
+    gsys._ck(lib.kkt_sync(h))
+    gsys._ck(lib.kkt_comm_barrier(h))
+    s_dt = C.c_double(time.perf_counter() - t0)
+    gsys._ck(lib.kkt_comm_max(h, C.byref(s_dt)))
+    tts = {"rhs": "README example (v_d = t c, f = c), zero initial guess",
+           "stopping_test": "gmres restart 10, rtol 1e-6 (library default), max 300",
+           "converged": bool(s_reason.value > 0), "iterations": int(s_its.value),
+           "seconds": s_dt.value}
 
     if rank != 0:
         return
