@@ -66,6 +66,33 @@ def build_problem(args):
                 schur=(args.schur_its, args.schur_emin, args.schur_emax))
 
 
+def readme_rhs(p):
+    """Rows of the README example (v_d = t c, f = c, zero initial state; README.md:34-56) for all
+    ``m`` blocks, as ``Instationary.linear_solve`` builds them (control.py:2991-3243): BE, or CN
+    with ``T_1`` / ``T_2`` applied."""
+    sd, m, tau, n_t = p["sd"], p["m"], p["tau"], p["n_t"]
+    X = sd.coords
+    cX = np.prod(np.cos(0.5 * np.pi * (X - 1.0)), axis=1)
+    Mc = sd.M @ cX
+    vd = np.stack([(i * tau) * Mc for i in range(n_t)])       # assemble(inner(v_d, test) dx)
+    ff = np.stack([Mc for _ in range(n_t)])
+    if p["CN"]:
+        h2 = 0.5 * tau
+        g0 = np.stack([h2 * (vd[i] + vd[i + 1]) for i in range(m)])
+        g1 = np.stack([h2 * (ff[i] + ff[i + 1]) for i in range(m)])
+    else:
+        g0 = np.stack([tau * vd[i] * (i < n_t - 1) for i in range(m)])
+        g1 = np.stack([tau * ff[i] * (i >= 1) for i in range(m)])
+    g0[:, p["nodes"]] = 0.0
+    g1[:, p["nodes"]] = 0.0
+    if p["CN"]:                                              # apply_T_1 / apply_T_2, :3242
+        t0_, t1_ = g0.copy(), g1.copy()
+        t0_[:-1] += g0[1:]
+        t1_[1:] += g1[:-1]
+        g0, g1 = t0_, t1_
+    return g0, g1
+
+
 def usable_cores():
     """Host cores this process may really use: the scheduler affinity, capped by the cgroup
     CPU quota (a one-GPU box grants a 16-core share of a much larger host)."""
@@ -307,29 +334,10 @@ def main():
     its, dt = run(args.steps)
     assert its == args.steps, (its, args.steps)
 
-    # ---- time to solution: the README right-hand side (v_d = t c, f = c, zero initial state),
-    # rows as control.py:2991-3243, library-default stopping test (gmres, restart 10,
-    # rtol 1e-6, control.py:3261-3266), at most 300 iterations
-    sd, m, tau, n_t = p["sd"], p["m"], p["tau"], p["n_t"]
-    X = sd.coords
-    cX = np.prod(np.cos(0.5 * np.pi * (X - 1.0)), axis=1)
-    Mc = sd.M @ cX
-    vd = np.stack([(i * tau) * Mc for i in range(n_t)])       # assemble(inner(v_d, test) dx)
-    ff = np.stack([Mc for _ in range(n_t)])
-    if p["CN"]:
-        h2 = 0.5 * tau
-        g0 = np.stack([h2 * (vd[i] + vd[i + 1]) for i in range(m)])
-        g1 = np.stack([h2 * (ff[i] + ff[i + 1]) for i in range(m)])
-    else:
-        g0 = np.stack([tau * vd[i] * (i < n_t - 1) for i in range(m)])
-        g1 = np.stack([tau * ff[i] * (i >= 1) for i in range(m)])
-    g0[:, p["nodes"]] = 0.0
-    g1[:, p["nodes"]] = 0.0
-    if p["CN"]:                                              # apply_T_1 / apply_T_2, :3242
-        t0_, t1_ = g0.copy(), g1.copy()
-        t0_[:-1] += g0[1:]
-        t1_[1:] += g1[:-1]
-        g0, g1 = t0_, t1_
+    # ---- time to solution: the README right-hand side, library-default stopping test (gmres,
+    # restart 10, rtol 1e-6, control.py:3261-3266), at most 300 iterations
+    sd = p["sd"]
+    g0, g1 = readme_rhs(p)
     lo = getattr(gsys, "_lo", 0)
     nloc = info["n_local"] // (2 * sd.n_dofs)
     r0, r1 = g0[lo:lo + nloc], g1[lo:lo + nloc]

@@ -12,17 +12,14 @@ ap.add_argument("--n", type=int, default=256)
 ap.add_argument("--n_t", type=int, default=64)
 ap.add_argument("--beta", type=float, default=1e-4)
 ap.add_argument("--max-it", type=int, default=300)
+ap.add_argument("--scheme", default="BE", choices=["BE", "CN"])
 a = ap.parse_args()
-p = common.heat_problem(n=a.n, n_t=a.n_t, beta=a.beta, T=2.0, CN=False, share=False)
+p = common.heat_problem(n=a.n, n_t=a.n_t, beta=a.beta, T=2.0, CN=a.scheme == "CN", share=False)
 sd, m, tau = p["sd"], p["m"], p["tau"]
 g = common.gpu_system(p)
-X = sd.coords
-c = np.cos(0.5 * np.pi * (X[:, 0] - 1.0)) * np.cos(0.5 * np.pi * (X[:, 1] - 1.0))
-# README example: v_d = t * c, f = c  (README.md:34-56); rows as control.py:2991-3130
-b_0 = np.stack([tau * (sd.M @ (i * tau * c)) * (i < a.n_t - 1) for i in range(a.n_t)])
-b_1 = np.stack([tau * (sd.M @ c) * (i >= 1) for i in range(a.n_t)])
-b_0[:, sd.boundary] = 0.0
-b_1[:, sd.boundary] = 0.0
+sys.path.insert(0, R)
+import bench
+b_0, b_1 = bench.readme_rhs(p)
 ap2 = os.environ.get("KKT_SWEEP", "coarse")
 SETS = {"coarse": ((8, 0.07, 2.1), (16, 0.02, 2.1), (30, 0.02, 2.1), (30, 0.005, 2.1),
                    (60, 0.002, 2.1), (100, 0.0007, 2.1)),
