@@ -244,7 +244,8 @@ def main():
     ap.add_argument("--mode", default="G", choices=["G", "S"])
     # Chebyshev substitute of the reference's AMG sub-solves: the lightest setting with which
     # GMRES(10) converges on cfg 2 (scripts/cfg2_convergence.py)
-    ap.add_argument("--schur-its", type=int, default=80)
+    # (CN: 140 sweeps -- 80 to 100 do not converge there, scripts/cfg2_convergence.py --scheme CN)
+    ap.add_argument("--schur-its", type=int, default=None)
     ap.add_argument("--schur-emin", type=float, default=0.0007)
     ap.add_argument("--schur-emax", type=float, default=2.1)
     ap.add_argument("--spmv-reps", type=int, default=50)
@@ -253,6 +254,8 @@ def main():
     ap.add_argument("--only-spmv", action="store_true",
                     help="time the KKT SpMV only (counter-collection passes)")
     args = ap.parse_args()
+    if args.schur_its is None:
+        args.schur_its = 140 if args.scheme == "CN" and args.workload != "stokes2d" else 80
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
