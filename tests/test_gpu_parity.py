@@ -275,3 +275,16 @@ def test_kat_stationary_incompressible():
     assert l2(th.M_v, u0[1] - p["z_ref"]) < 1.0e-13
     assert l2(th.M_p, demean(th.M_p, u1[1]) - demean(th.M_p, p["p_ref"])) < 5.0e-13   # see
     assert l2(th.M_p, demean(th.M_p, u1[0]) - demean(th.M_p, p["mu_ref"])) < 1.0e-13  # oracle KAT
+
+
+@pytest.mark.parametrize("CN", [False, True])
+def test_preconditioner_parity_high_degree(CN):
+    """The default benchmark preconditioner runs 80-140 Chebyshev sweeps per sub-solve: sweep
+    programs of several thousand phases.  Same parity as at low degree."""
+    p = common.heat_problem(n=48, n_t=8, CN=CN)
+    osys = common.oracle_system(p)
+    schur = (120, 0.002, 2.1)
+    x = common.rng_vector(osys.N)
+    ref = osys.pc_apply(common.oracle_pc(p, MASS, schur), x)
+    got = common.gpu_system(p).pc_apply(x, common.gpu_pc(p, MASS, schur))
+    assert common.rel_err(got, ref) < 1e-9
