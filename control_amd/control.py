@@ -21,16 +21,46 @@ import scipy.sparse as sp
 from .blocks import (conform_to, instationary_blocks, instationary_incompressible_blocks,
                      stationary_blocks, stationary_incompressible_blocks)
 
-__all__ = ["Instationary", "Stationary", "GpuBackend"]
+__all__ = ["Instationary", "Stationary", "GpuBackend", "suggest_chebyshev"]
+
+
+def suggest_chebyshev(D, M, shift, nodes, safety=2.0, max_dofs=400000):
+    """Degree and interval ``(its, emin, emax)`` of the Jacobi-Chebyshev sweeps that stand in
+    for the reference's AMG cycles on ``L = D + shift * M`` (Dirichlet rows removed).
+
+    The interval is the spectrum of ``diag(L)^-1 L`` (largest eigenvalue by Lanczos, smallest
+    by shift-invert Lanczos, both widened by 5 %); the degree is ``safety * sqrt(emax / emin)``.
+    On the 256^2 P1 heat-control system (interior levels, shift tau / sqrt(beta)) this gives
+    124 sweeps on [5.5e-4, 2.1]; the measured minimum for GMRES(10) to converge is 80 sweeps on
+    [7e-4, 2.1], and 80 to 140 sweeps reach the solution in about the same time (DESIGN.md
+    section 8).  Smaller systems prefer the larger factor (64^2 x 16: 2.25 is fastest).  Host-side,
+    SciPy: a sparse LU of one spatial block, so only for blocks up to ``max_dofs`` rows."""
+    import scipy.sparse.linalg as sla
+    L = sp.csr_matrix(D) + float(shift) * sp.csr_matrix(M)
+    keep = np.setdiff1d(np.arange(L.shape[0]), np.asarray(nodes, dtype=np.int64))
+    if len(keep) > max_dofs:
+        raise ValueError("suggest_chebyshev: block too large for a host-side eigenvalue "
+                         "estimate; pass (its, emin, emax) explicitly")
+    L = L[keep][:, keep].tocsc()
+    d = 1.0 / np.sqrt(L.diagonal())
+    S = sp.diags(d) @ (0.5 * (L + L.T)) @ sp.diags(d)      # symmetric part, Jacobi-scaled
+    emax = float(sla.eigsh(S, k=1, which="LA", return_eigenvectors=False, tol=1e-3)[0])
+    emin = float(sla.eigsh(S.tocsc(), k=1, sigma=0.0, which="LM", return_eigenvectors=False,
+                           tol=1e-3)[0])
+    emin, emax = 0.95 * emin, 1.05 * emax
+    return int(np.ceil(safety * np.sqrt(emax / emin))), emin, emax
 
 
 class GpuBackend:
-    """The classes ``linear_solve`` instantiates (``preconditioner.preconditioner`` names)."""
+    """The classes ``linear_solve`` instantiates (``preconditioner.preconditioner`` names).
 
-    def __init__(self, schur=(8, 0.07, 2.1), device=0):
+    ``schur``: ``(its, emin, emax)`` of the Chebyshev sweeps that replace the reference's AMG
+    sub-solves, or ``"auto"`` (default): ``suggest_chebyshev`` on the first time level's matrix."""
+
+    def __init__(self, schur="auto", device=0, kp=None):
         from . import multiblock as mb
         self._mb, self.schur, self.device = mb, schur, device
-        self.kp = schur                  # Chebyshev replacement of the AMG cycle on K_p
+        self.kp = kp if kp is not None else schur   # replacement of the AMG cycle on K_p
         self.DirichletBCNullspace = mb.DirichletBCNullspace
         self.ConstantNullspace = mb.ConstantNullspace
 
@@ -40,10 +70,25 @@ class GpuBackend:
     def construct_pc(self, kind, M, block_01, block_10, n_t, tau, beta, nodes, lambda_v_bounds,
                      epsilon):
         mb = self._mb
+        schur = self.schur
+        if isinstance(schur, str):
+            # "auto": the matrix of the interior time levels (the first and last levels carry a
+            # smaller shift -- control.py:2241-2327 -- and a wider spectrum; they are 2 of n_t)
+            shift = {"stationary": 1.0 / np.sqrt(beta), "BE": tau / np.sqrt(beta),
+                     "CN": 0.5 * tau / np.sqrt(beta)}[kind]
+            schur = suggest_chebyshev(block_10[(0, 0)], M, shift, nodes)
+            self.resolved_schur = schur
         return mb.SchurPC(kind=kind, M=M, beta=beta, bc_nodes=nodes,
                           mass=mb.ChebSpec(20, *lambda_v_bounds),      # control.py:1967-1982
-                          schur=mb.ChebSpec(*self.schur), n_t=n_t, tau=tau, epsilon=epsilon)
+                          schur=mb.ChebSpec(*schur), n_t=n_t, tau=tau, epsilon=epsilon)
 
+
+    def _kp_spec(self, inner_pc):
+        """Sweeps on ``K_p``: as given, or (``"auto"``) degree and lower bound of the velocity
+        sub-solves on [emin, 2.1] (P1 pressure stiffness, Jacobi-scaled)."""
+        if isinstance(self.kp, str):
+            return (inner_pc.schur.its, inner_pc.schur.emin, 2.1)
+        return self.kp
 
     def construct_stokes_pc(self, th, blocks, n_t, tau, beta, CN, lambda_v_bounds,
                             lambda_p_bounds, epsilon):
@@ -55,10 +100,11 @@ class GpuBackend:
                                       nullspace_1=(nsv,) * m, CN=CN)
         comm = self.MultiBlockSystem(th.n_p, th.n_p, *blocks["commutator"], n_blocks_00=m,
                                      n_blocks_11=m)
-        inner_pc = self.construct_pc("CN" if CN else "BE", th.M_v, None, None, n_t, tau, beta,
-                                     th.boundary_v, lambda_v_bounds, epsilon)
+        inner_pc = self.construct_pc("CN" if CN else "BE", th.M_v, blocks["inner"][1],
+                                     blocks["inner"][2], n_t, tau, beta, th.boundary_v,
+                                     lambda_v_bounds, epsilon)
         return mb.StokesPC(inner=inner, inner_pc=inner_pc, commutator=comm, B=th.B, K_p=th.K_p,
-                           M_p=th.M_p, kp=mb.ChebSpec(*self.kp),
+                           M_p=th.M_p, kp=mb.ChebSpec(*self._kp_spec(inner_pc)),
                            mp=mb.ChebSpec(20, *lambda_p_bounds), n_p_blocks=m, b_scale=tau,
                            post_scale=1.0 / tau**2, cn=CN)
 
@@ -75,7 +121,7 @@ class GpuBackend:
         inner_pc = self.construct_pc("stationary", th.M_v, i01, i10, 1, 0.0, beta,
                                      th.boundary_v, lambda_v_bounds, 0.0)
         return mb.StokesPC(inner=inner, inner_pc=inner_pc, commutator=comm, B=th.B, K_p=th.K_p,
-                           M_p=th.M_p, kp=mb.ChebSpec(*self.kp),
+                           M_p=th.M_p, kp=mb.ChebSpec(*self._kp_spec(inner_pc)),
                            mp=mb.ChebSpec(20, *lambda_p_bounds))
 
 

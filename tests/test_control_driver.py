@@ -424,3 +424,42 @@ def test_stationary_navier_stokes_picard_on_the_gpu():
     assert len(out[0][0]) == len(out[1][0])
     assert np.abs(out[0][1] - out[1][1]).max() < 1e-7
     assert np.abs(out[0][2] - out[1][2]).max() < 1e-8
+
+
+# ------------------------------------------------------ automatic Chebyshev parameters
+
+def test_suggested_chebyshev_parameters_make_the_solve_converge():
+    """``suggest_chebyshev``: interval from the spectrum of the Jacobi-scaled interior-level
+    matrix, degree 1.5 sqrt(kappa).  With it the oracle converges on a 64^2 x 16 heat-control
+    system on which 8 sweeps on [0.07, 2.1] do not (the situation of cfg 2)."""
+    from control_amd.control import suggest_chebyshev
+    p = common.heat_problem(n=64, n_t=16, beta=1.0e-4, T=2.0)
+    sd, tau, m = p["sd"], p["tau"], p["m"]
+    its, emin, emax = suggest_chebyshev(p["blocks"][2][(1, 1)], sd.M, tau / np.sqrt(p["beta"]),
+                                        p["nodes"])
+    assert 25 <= its <= 60 and 1e-3 < emin < 1e-2 and 2.0 < emax < 2.3
+    import bench
+    b_0, b_1 = bench.readme_rhs(p)
+    sp_ = {"linear_solver": "gmres", "gmres_restart": 10, "relative_tolerance": 1.0e-6,
+           "absolute_tolerance": 0.0, "maximum_iterations": 60, "monitor_convergence": False}
+    osys = common.oracle_system(p)
+    v, z = np.zeros((m, sd.n_dofs)), np.zeros((m, sd.n_dofs))
+    r = osys.solve(v, z, b_0, b_1, solver_parameters=sp_,
+                   pc_fn=common.oracle_pc(p, (20, 0.5, 2.0), (its, emin, emax)))
+    assert r.reason > 0 and r.its <= 40
+    with pytest.raises(RuntimeError):
+        osys.solve(np.zeros_like(v), np.zeros_like(z), b_0, b_1, solver_parameters=sp_,
+                   pc_fn=common.oracle_pc(p, (20, 0.5, 2.0), (8, 0.07, 2.1)))
+
+
+@pytest.mark.gpu
+def test_gpu_backend_default_parameters_converge():
+    """``GpuBackend()`` without arguments picks the sweeps itself."""
+    from control_amd.control import GpuBackend
+    ctl, disc, ref_v, ref_zeta = common.mms_heat_control(32, False)
+    be = GpuBackend()
+    ksp = ctl.linear_solve(solver_parameters=common.MMS_SOLVER_PARAMETERS,
+                           lambda_v_bounds=(0.5, 2.0), backend=be)
+    assert ksp.getConvergedReason() > 0 and be.resolved_schur[0] >= 8
+    ev, ez = common.mms_errors(ctl, disc, ref_v, ref_zeta)
+    assert ev < 1e-2 and ez < 1e-2
