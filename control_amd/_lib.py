@@ -104,6 +104,8 @@ SIGNATURES = {
                                  C.POINTER(C.c_float)]),
     "kkt_time_pc_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.POINTER(C.c_float)]),
+    "kkt_time_pc_sweeps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float),
+                                     C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "kkt_get_info": (C.c_int, [C.c_void_p, C.POINTER(Info)]),
     "kkt_comm_unique_id": (C.c_int, [C.c_void_p]),
     "kkt_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -268,6 +268,14 @@ int kkt_time_pc_apply(kkt_handle h, const double *d_x, double *d_y, int reps, fl
     KKT_TRY(h, time_loop(S, true, d_x, d_y, reps, ms));
 }
 
+int kkt_time_pc_sweeps(kkt_handle h, const double *d_x, double *d_y, float *ms, int *launches,
+                       int64_t *phases) {
+    KKT_TRY(h, {
+        if (!d_x || !d_y || !ms || !launches || !phases) fail(KKT_ERR_ARG, "null argument");
+        S.pc_apply_timed(d_x, d_y, ms, launches, phases);
+    });
+}
+
 int kkt_get_info(kkt_handle h, kkt_info *info) {
     KKT_TRY(h, {
         if (!info) fail(KKT_ERR_ARG, "null info");

@@ -122,6 +122,22 @@ void System::pc_apply(const double *d_x, double *d_y) {
     ns_pc_post(d_y, out, d_x);
 }
 
+// measurement variant of pc_apply: built-in preconditioner run as plain launches with events
+// around its persistent programs (kkt_time_pc_sweeps)
+void System::pc_apply_timed(const double *d_x, double *d_y, float *ms, int *launches,
+                            int64_t *phases) {
+    if (!finalized) fail(KKT_ERR_STATE, "system not finalized");
+    if (!pc) fail(KKT_ERR_STATE, "no built-in preconditioner");
+    if (sharded) fail(KKT_ERR_STATE, "kkt_time_pc_sweeps on a time-sharded handle");
+    if (pc_stale) {
+        pc->values_changed();
+        pc_stale = false;
+    }
+    ns_project(pc->in(), d_x);
+    pc->time_programs(ms, launches, phases);
+    ns_pc_post(d_y, pc->out(), d_x);
+}
+
 namespace {
 
 struct Conv {   // KSPConvergedDefault

@@ -326,6 +326,40 @@ void SchurPC::debug_read(unsigned long long *out, int n) {
     HIPCHK(hipMemset(d_err_ + 64, 0, (size_t)n * 8));
 }
 
+// One application as plain launches with an event pair around every persistent program.
+void SchurPC::time_programs(float *ms, int *launches, int64_t *phases) {
+    hipStream_t st = S_.stream;
+    *ms = 0.f;
+    *launches = 0;
+    *phases = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+    size_t k = 0;
+    while (k < steps_.size()) {
+        if (steps_[k].kind == PcStep::PROG) {
+            hipEvent_t a, b;
+            HIPCHK(hipEventCreate(&a));
+            HIPCHK(hipEventCreate(&b));
+            HIPCHK(hipEventRecord(a, st));
+            replay(k, k + 1);
+            HIPCHK(hipEventRecord(b, st));
+            evs.push_back({a, b});
+            *launches += 1;
+            *phases += steps_[k].nphases;
+        } else {
+            replay(k, k + 1);
+        }
+        ++k;
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    for (auto &e : evs) {
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, e.first, e.second));
+        *ms += t;
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+}
+
 void SchurPC::check() {
     if (!d_err_) return;
     unsigned e = 0;

@@ -38,6 +38,12 @@ class PcBase {
     virtual void values_changed() {}
     virtual void check() {}
     virtual void debug_read(unsigned long long *, int) {}
+    // measurement: time the persistent programs of the next run() with events
+    virtual void time_programs(float *ms, int *launches, int64_t *phases) {
+        *ms = 0.f;
+        *launches = 0;
+        *phases = 0;
+    }
 };
 
 class SchurPC : public PcBase {
@@ -51,6 +57,7 @@ class SchurPC : public PcBase {
     void values_changed() override;
     void check() override;   // throws if a persistent row program reported a time-out
     void debug_read(unsigned long long *out, int n) override;   // diagnostic builds (KKT_STAMPS)
+    void time_programs(float *ms, int *launches, int64_t *phases) override;
     int bc_set() const { return bc_set_; }
     int64_t n_launches() const { return (int64_t)steps_.size(); }
 

@@ -212,6 +212,7 @@ struct System {
     // -- operations on device vectors of n_local doubles
     void apply(const double *d_x, double *d_y);
     void pc_apply(const double *d_x, double *d_y);
+    void pc_apply_timed(const double *d_x, double *d_y, float *ms, int *launches, int64_t *phases);
     void solve(const double *d_b, double *d_u, int *its, int *reason, double *rnorm,
                double *hist, int hist_cap, int *hist_len);
     void ensure_workspace(int restart, bool flexible);

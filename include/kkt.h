@@ -220,6 +220,11 @@ int kkt_sync(kkt_handle h);
  * events on the library's own stream; *ms = total elapsed milliseconds. */
 int kkt_time_apply(kkt_handle h, const double *d_x, double *d_y, int reps, float *ms);
 int kkt_time_pc_apply(kkt_handle h, const double *d_x, double *d_y, int reps, float *ms);
+/* One preconditioner application with HIP events around every persistent sweep program of the
+ * built-in preconditioner: *ms = their summed duration, *launches / *phases = how many programs
+ * and dependent phases ran (0 when the preconditioner has no such programs).  Measurement only. */
+int kkt_time_pc_sweeps(kkt_handle h, const double *d_x, double *d_y, float *ms, int *launches,
+                       int64_t *phases);
 
 /* Byte accounting of the stored operator ("algorithmic bytes"). */
 typedef struct kkt_info {
