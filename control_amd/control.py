@@ -157,12 +157,14 @@ class Instationary:
 
     def __init__(self, disc, forward_operator=None, *, desired_state=None, force_f=None,
                  beta=1.0e-3, initial_condition=None, time_interval=(0.0, 1.0), CN=True,
-                 n_t=20, bcs_v=None):
+                 n_t=20, bcs_v=None, forward_jacobian=None):
         self._th = disc if hasattr(disc, "M_v") else None
         if self._th is not None:
             disc = _VelocitySpace(disc)
         self._disc = disc
         self._forward = forward_operator or (lambda v, t: disc.K)
+        self._jacobian = forward_jacobian
+        self._Gauss_Newton = False
         self._desired_state, self._force_f = desired_state, force_f
         self._beta = float(beta)
         self._initial_condition = initial_condition
@@ -175,6 +177,16 @@ class Instationary:
         if self._th is not None:
             self._p = np.zeros((n_t, self._th.n_p))
             self._mu = np.zeros((n_t, self._th.n_p))
+
+    def set_Gauss_Newton(self, Gauss_Newton=True):   # control.py:1835-1836
+        if Gauss_Newton and self._jacobian is None:
+            raise ValueError("Gauss-Newton needs forward_jacobian")
+        self._Gauss_Newton = bool(Gauss_Newton)
+
+    def construct_D_v(self, v_n_help, t):    # control.py:1887-1896
+        """``forward_form(trial, test, v, t)`` assembled, or after ``set_Gauss_Newton()`` its
+        Gateaux derivative in ``v`` in the direction of ``trial`` (``forward_jacobian(v, t)``)."""
+        return (self._jacobian if self._Gauss_Newton else self._forward)(v_n_help, t)
 
     # -- control.py:1898-1941
     def _times(self):
@@ -303,9 +315,9 @@ class Instationary:
         if check_v_d:
             v_d = self.construct_v_d()
         v_old = self._v
-        D = [conform_to(self._forward(v_old[i], t_0 + i * tau), M) for i in range(n_t)]
+        D = [conform_to(self.construct_D_v(v_old[i], t_0 + i * tau), M) for i in range(n_t)]
         b00, b01, b10, b11, m = instationary_blocks(M, D, tau, beta, n_t, CN)
-        D_0 = conform_to(self._forward(v_0, t_0), M)
+        D_0 = conform_to(self.construct_D_v(v_0, t_0), M)
 
         b_0, b_1 = self._velocity_rows(D, D_0, v_0, v_d, f, check_v_d, check_f)
         if CN:
@@ -348,7 +360,7 @@ class Instationary:
         disc, n_t, beta, CN = self._disc, self._n_t, self._beta, self._CN
         M, nodes = disc.M, disc.boundary
         t_0, _, tau = self._times()
-        D = [sp.csr_matrix(self._forward(v_old[i], t_0 + i * tau)) for i in range(n_t)]
+        D = [sp.csr_matrix(self.construct_D_v(v_old[i], t_0 + i * tau)) for i in range(n_t)]
         if CN:
             m, h = n_t - 1, 0.5 * tau
             r0 = np.zeros((m, disc.n_dofs))
@@ -364,7 +376,7 @@ class Instationary:
         else:
             r0 = np.zeros((n_t, disc.n_dofs))
             r1 = np.zeros((n_t, disc.n_dofs))
-            D_0 = sp.csr_matrix(self._forward(v_0, t_0))
+            D_0 = sp.csr_matrix(self.construct_D_v(v_0, t_0))
             for i in range(n_t):
                 Dz = tau * (D[i].T @ zeta_old[i]) + M @ zeta_old[i]
                 r0[i] = (tau * v_d[i] - tau * (M @ v_old[i]) - Dz + M @ zeta_old[i + 1]
@@ -453,9 +465,9 @@ class Instationary:
         if check_v_d:
             v_d = self.construct_v_d()
         v_old = self._v
-        D = [conform_to(self._forward(v_old[i], t_0 + i * tau), th.M_v) for i in range(n_t)]
+        D = [conform_to(self.construct_D_v(v_old[i], t_0 + i * tau), th.M_v) for i in range(n_t)]
         Dp = [conform_to(fwd_p(v_old[i], t_0 + i * tau), th.M_p) for i in range(n_t)]
-        D_0 = conform_to(self._forward(v_0, t_0), th.M_v)
+        D_0 = conform_to(self.construct_D_v(v_0, t_0), th.M_v)
         bl = instationary_incompressible_blocks(th.M_v, D, th.B, th.M_p, Dp, tau, beta, n_t, CN)
         m = bl["m"]
         b_0_0, b_0_1 = self._velocity_rows(D, D_0, v_0, v_d, f, check_v_d, check_f)

@@ -227,6 +227,41 @@ def test_instationary_picard_loop_on_the_gpu(CN):
     assert np.abs(out[0][2] - out[1][2]).max() < 1e-9
 
 
+@pytest.mark.parametrize("CN", [False, True])
+def test_instationary_gauss_newton_reaches_a_smaller_residual_than_it_starts_from(CN):
+    """``Instationary.set_Gauss_Newton`` (``control.py:1835-1836``, ``construct_D_v``
+    ``:1887-1896``): every ``D_v`` of the driver -- operator blocks, boundary lifting and the
+    residual -- becomes the Gateaux derivative of the forward form.  For the cubic reaction
+    term ``(2 + 0.5 v^2) v`` that is ``grad-grad + (2 + 1.5 v^2) mass``; the loop is the
+    reference's (only the stationary variant is exercised by its tests,
+    ``test/test_control.py:921``), so the checks are structural: the switch changes the
+    blocks, refuses to engage without a derivative, and the loop still contracts."""
+    from control_amd.control import Instationary
+    ctl, disc = _reaction_heat_control(CN)
+    with pytest.raises(ValueError):
+        ctl.set_Gauss_Newton()
+
+    def jacobian(v_old, t):
+        return disc.K + disc.weighted_mass(
+            lambda lam, cells: 2.0 + 1.5 * (v_old[cells] @ lam.T) ** 2)
+    picard = ctl._forward
+    ctl = Instationary(disc, picard, desired_state=ctl._desired_state, beta=1.0e-2, CN=CN,
+                       n_t=5, time_interval=(0.0, 1.0), forward_jacobian=jacobian)
+    v = np.linspace(0.0, 1.0, disc.n_dofs)
+    A_picard = ctl.construct_D_v(v, 0.0)
+    ctl.set_Gauss_Newton()
+    A_newton = ctl.construct_D_v(v, 0.0)
+    assert abs(A_newton - A_picard).max() > 1e-6
+    assert abs(A_newton - jacobian(v, 0.0)).max() == 0.0
+    norms = ctl.non_linear_solve(solver_parameters=KAT_SP, lambda_v_bounds=(0.5, 2.0),
+                                 max_non_linear_iter=8, relative_non_linear_tol=1.0e-6,
+                                 absolute_non_linear_tol=0.0,
+                                 backend=common.OracleBackend(schur=(40, 0.02, 2.2)))
+    assert len(norms) >= 2 and norms[-1] < 0.2 * norms[0]
+    ctl.set_Gauss_Newton(False)
+    assert abs(ctl.construct_D_v(v, 0.0) - A_picard).max() == 0.0
+
+
 def _mms_poisson_control(N):
     """``test/test_control.py:122-230``: stationary Poisson control, P1 on
     ``UnitSquareMesh(N, N)``, beta = 1e-3, manufactured state and adjoint."""
