@@ -24,8 +24,13 @@ ap2 = os.environ.get("KKT_SWEEP", "coarse")
 SETS = {"coarse": ((8, 0.07, 2.1), (16, 0.02, 2.1), (30, 0.02, 2.1), (30, 0.005, 2.1),
                    (60, 0.002, 2.1), (100, 0.0007, 2.1)),
         "fine": ((60, 0.001, 2.1), (80, 0.001, 2.1), (80, 0.0007, 2.1), (100, 0.001, 2.1),
-                 (100, 0.0007, 2.1), (140, 0.0005, 2.1), (140, 0.0007, 2.1))}
+                 (100, 0.0007, 2.1), (140, 0.0005, 2.1), (140, 0.0007, 2.1)),
+        # lower end at / below the smallest eigenvalue suggest_chebyshev reports (5.5e-4)
+        "interval": ((90, 0.00055, 2.1), (100, 0.00055, 2.1), (124, 0.00055, 2.1),
+                     (110, 0.0004, 2.1), (124, 0.0004, 2.1), (160, 0.0004, 2.1),
+                     (124, 0.0003, 2.1), (180, 0.0003, 2.1))}
 for ksp, restart in ((("gmres", 10), ("fgmres", 30)) if ap2 == "coarse" else
+                     (("gmres", 10),) if ap2 == "interval" else
                      (("gmres", 10), ("gmres", 30))):
     for schur in SETS[ap2]:
         pc = common.gpu_pc(p, (20, 0.5, 2.0), schur)
