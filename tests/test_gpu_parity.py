@@ -288,3 +288,32 @@ def test_preconditioner_parity_high_degree(CN):
     ref = osys.pc_apply(common.oracle_pc(p, MASS, schur), x)
     got = common.gpu_system(p).pc_apply(x, common.gpu_pc(p, MASS, schur))
     assert common.rel_err(got, ref) < 1e-9
+
+
+@pytest.mark.parametrize("CN", [False, True])
+def test_timed_sweep_programs_give_the_preconditioner_result(CN):
+    """``kkt_time_pc_sweeps`` (the measurement entry point behind ``roofline_sweeps`` of
+    bench.py) replays the preconditioner step by step with a HIP event pair around every
+    persistent sweep launch: the result is the preconditioner's, bit for bit, and the counts
+    are the two time sweeps with ``n_levels * (its + 1)`` phases each."""
+    import ctypes as C
+    from control_amd import _lib
+    p = common.heat_problem(n=24, n_t=6, CN=CN)
+    gsys = common.gpu_system(p)
+    gpc = common.gpu_pc(p, MASS, (12, 0.05, 2.2))
+    x = common.rng_vector(2 * p["m"] * p["sd"].n_dofs)
+    ref = gsys.pc_apply(x, gpc)
+    lib, h = gsys._lib, gsys.handle
+    d_x, d_y = C.c_void_p(), C.c_void_p()
+    gsys._ck(lib.kkt_vec_alloc(h, C.byref(d_x)))
+    gsys._ck(lib.kkt_vec_alloc(h, C.byref(d_y)))
+    a, pa = _lib.f64(x)
+    gsys._ck(lib.kkt_vec_upload(h, d_x, pa))
+    ms, launches, phases = C.c_float(), C.c_int(), C.c_int64()
+    gsys._ck(lib.kkt_time_pc_sweeps(h, d_x, d_y, C.byref(ms), C.byref(launches),
+                                    C.byref(phases)))
+    got = np.zeros_like(x)
+    gsys._ck(lib.kkt_vec_download(h, d_y, got.ctypes.data_as(_lib.c_f64p)))
+    assert np.array_equal(got, ref)
+    assert launches.value >= 2 and ms.value > 0.0
+    assert phases.value >= 2 * (p["m"] - 1) * 13 and phases.value <= 2 * (p["m"] + 1) * 14
