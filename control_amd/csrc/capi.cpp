@@ -138,8 +138,8 @@ int kkt_set_pc_identity(kkt_handle h) {
 int kkt_set_krylov(kkt_handle h, int type, int pc_side, int restart, double rtol, double atol,
                    double divtol, int max_it) {
     KKT_TRY(h, {
-        if (type != KKT_KSP_GMRES && type != KKT_KSP_FGMRES)
-            fail(KKT_ERR_ARG, "linear_solver must be gmres or fgmres");
+        if (type != KKT_KSP_GMRES && type != KKT_KSP_FGMRES && type != KKT_KSP_MINRES)
+            fail(KKT_ERR_ARG, "linear_solver must be gmres, fgmres or minres");
         if (restart < 1 || max_it < 0 || rtol < 0 || atol < 0) fail(KKT_ERR_ARG, "bad KSP options");
         S.ksp.type = type;
         S.ksp.pc_side = pc_side;

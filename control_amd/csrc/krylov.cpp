@@ -154,9 +154,135 @@ struct Conv {   // KSPConvergedDefault
 
 }  // namespace
 
+// Preconditioned MINRES, the classic KSPSolve_MINRES of PETSc (<= 3.18): Lanczos on A in the
+// B inner product, one Givens rotation per step, monitored norm ||B r_0|| prod |s_k|.  B must
+// be symmetric positive definite (a user callback or the identity: the block-Schur
+// descriptors are block triangular and are reported as KKT_DIVERGED_INDEFINITE_PC when they
+// produce r.Br < 0).  Never used by the reference; reachable through the same
+// "linear_solver" string, so it is here.  Two host reads per iteration (alpha, then r.z).
+void System::solve_minres(const double *d_b, double *d_u, int *its_out, int *reason_out,
+                          double *rnorm_out, double *hist, int hist_cap, int *hist_len) {
+    if (ksp.pc_side == KKT_PC_RIGHT) fail(KKT_ERR_ARG, "minres supports left preconditioning only");
+    ensure_workspace(std::max(ksp.restart, 9), false);
+    pc_cb_failed = false;
+    info.last_pc_applies = 0;
+    info.last_op_applies = 0;
+    auto Vp = [&](int k) { return d_V + (size_t)k * vec_stride; };
+    double *R = Vp(0), *Z = Vp(1), *U = Vp(2), *V = Vp(3), *W = Vp(4), *UOLD = Vp(5),
+           *VOLD = Vp(6), *WOLD = Vp(7), *WOOLD = Vp(8);
+    auto dot = [&](const double *a, const double *c) {
+        const double *L[1] = {c};
+        mdot(a, L, 1, d_hcol);
+        HIPCHK(hipMemcpyAsync(h_pinned, d_hcol, sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        return h_pinned[0];
+    };
+    auto axpy = [&](double *y, double a, const double *x) { launch_axpby(stream, y, a, x, 1.0, n_local); };
+    auto scaled = [&](double *y, double a, const double *x) { launch_axpby(stream, y, a, x, 0.0, n_local); };
+    int nh = 0;
+    auto log = [&](double rn) {
+        if (hist && nh < hist_cap) hist[nh] = rn;
+        ++nh;
+    };
+    ns_project(d_u, d_u);
+    ns_project(d_rhs, d_b);
+    const double *b = d_rhs;
+    sync();
+    const auto t_begin = std::chrono::steady_clock::now();
+    const double haptol = 1.0e-50;
+
+    pc_apply(b, Z);
+    const Conv conv(ksp.rtol, ksp.atol, ksp.divtol, std::sqrt(dot(Z, Z)));
+    for (double *p : {UOLD, VOLD, W, WOLD, WOOLD}) launch_fill(stream, p, 0.0, n_local);
+    apply(d_u, R);
+    launch_axpby(stream, R, 1.0, b, -1.0, n_local);   // r = b - A x
+    pc_apply(R, Z);
+    double np = std::sqrt(dot(Z, Z));
+    double dp = dot(R, Z);
+    int its = 0, reason = 0;
+    if (dp < haptol && np > haptol) {
+        reason = KKT_DIVERGED_INDEFINITE_PC;
+    } else {
+        log(np);
+        reason = conv(np);
+    }
+    if (!reason) {
+        double beta = std::sqrt(std::fabs(dp)), eta = beta;
+        double c = 1.0, cold = 1.0, s = 0.0, sold = 0.0;
+        scaled(V, 1.0 / beta, R);
+        scaled(U, 1.0 / beta, Z);
+        int i = 0;
+        while (i < ksp.max_it) {
+            its = i + 1;
+            apply(U, R);
+            const double alpha = dot(U, R);
+            pc_apply(R, Z);
+            axpy(R, -alpha, V);
+            axpy(Z, -alpha, U);
+            axpy(R, -beta, VOLD);
+            axpy(Z, -beta, UOLD);
+            const double betaold = beta;
+            dp = dot(R, Z);
+            beta = std::sqrt(std::fabs(dp));
+            const double coold = cold, soold = sold;
+            cold = c;
+            sold = s;
+            const double rho0 = cold * alpha - coold * sold * betaold;
+            const double rho1 = std::sqrt(rho0 * rho0 + beta * beta);
+            const double rho2 = sold * alpha + coold * cold * betaold;
+            const double rho3 = soold * betaold;
+            c = rho0 / rho1;
+            s = beta / rho1;
+            {   // w_oold <- w_old, w_old <- w; the new w goes into the buffer w_oold leaves
+                double *scratch = WOOLD;
+                WOOLD = WOLD;
+                WOLD = W;
+                W = scratch;
+            }
+            launch_copy(stream, W, U, n_local);
+            axpy(W, -rho2, WOLD);
+            axpy(W, -rho3, WOOLD);
+            scaled(W, 1.0 / rho1, W);
+            axpy(d_u, c * eta, W);
+            if (dp < haptol) {   // converged or indefinite operator: true residual norm
+                apply(d_u, VOLD);
+                axpy(VOLD, -1.0, b);
+                np = std::sqrt(dot(VOLD, VOLD));
+            } else {
+                np *= std::fabs(s);
+            }
+            log(np);
+            reason = conv(np);
+            if (reason) break;
+            if (dp < haptol) {
+                reason = KKT_DIVERGED_INDEFINITE_MAT;
+                break;
+            }
+            eta = -s * eta;
+            std::swap(VOLD, V);
+            std::swap(UOLD, U);
+            scaled(V, 1.0 / beta, R);
+            scaled(U, 1.0 / beta, Z);
+            ++i;
+        }
+        if (!reason) reason = KKT_DIVERGED_ITS;
+    }
+    ns_project(d_u, d_u);
+    sync();
+    info.last_solve_ms =
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    if (its_out) *its_out = its;
+    if (reason_out) *reason_out = reason;
+    if (rnorm_out) *rnorm_out = np;
+    if (hist_len) *hist_len = nh;
+    if (pc_cb_failed) fail(KKT_ERR_CALLBACK, "Error encountered in preconditioner callback");
+}
+
 void System::solve(const double *d_b, double *d_u, int *its_out, int *reason_out,
                    double *rnorm_out, double *hist, int hist_cap, int *hist_len) {
     if (!finalized) fail(KKT_ERR_STATE, "system not finalized");
+    if (ksp.type == KKT_KSP_MINRES)
+        return solve_minres(d_b, d_u, its_out, reason_out, rnorm_out, hist, hist_cap, hist_len);
     const bool flexible = ksp.type == KKT_KSP_FGMRES;
     bool right = flexible;
     if (!flexible && ksp.pc_side == KKT_PC_RIGHT) right = true;

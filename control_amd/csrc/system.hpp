@@ -215,6 +215,8 @@ struct System {
     void pc_apply_timed(const double *d_x, double *d_y, float *ms, int *launches, int64_t *phases);
     void solve(const double *d_b, double *d_u, int *its, int *reason, double *rnorm,
                double *hist, int hist_cap, int *hist_len);
+    void solve_minres(const double *d_b, double *d_u, int *its, int *reason, double *rnorm,
+                      double *hist, int hist_cap, int *hist_len);
     void ensure_workspace(int restart, bool flexible);
     // reductions over the whole (distributed) vector; results in device memory
     void mdot(const double *w, const double *const *V, int nv, double *d_out);

@@ -22,7 +22,7 @@ __all__ = ["Nullspace", "NoneNullspace", "ConstantNullspace", "DirichletBCNullsp
            "ChebSpec"]
 
 Q00, Q01, Q10, Q11 = 0, 1, 2, 3
-_KSP_TYPES = {"gmres": 0, "fgmres": 1}
+_KSP_TYPES = {"gmres": 0, "fgmres": 1, "minres": 2}
 _PC_SIDES = {"left": 0, "right": 1, 0: 0, 1: 1}
 
 
@@ -404,7 +404,7 @@ class MultiBlockSystem:
         ksp_type = sp.get("linear_solver", "fgmres")
         if ksp_type not in _KSP_TYPES:
             raise ValueError(f"linear_solver {ksp_type!r} is not available "
-                             "(gmres and fgmres are)")
+                             "(gmres, fgmres and minres are)")
         side = _PC_SIDES[sp["pc_side"]] if "pc_side" in sp else -1
         divtol = sp.get("divergence limit", None)
         max_it = int(sp.get("maximum_iterations", 1000))

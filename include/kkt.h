@@ -43,7 +43,7 @@ enum {
 enum { KKT_Q00 = 0, KKT_Q01 = 1, KKT_Q10 = 2, KKT_Q11 = 3 };
 
 /* Krylov methods (`solver_parameters["linear_solver"]`, preconditioner.py:733) */
-enum { KKT_KSP_GMRES = 0, KKT_KSP_FGMRES = 1 };
+enum { KKT_KSP_GMRES = 0, KKT_KSP_FGMRES = 1, KKT_KSP_MINRES = 2 };
 /* `solver_parameters["pc_side"]` (preconditioner.py:735-736); DEFAULT = the method's own */
 enum { KKT_PC_SIDE_DEFAULT = -1, KKT_PC_LEFT = 0, KKT_PC_RIGHT = 1 };
 
@@ -55,7 +55,9 @@ enum {
     KKT_DIVERGED_ITS = -3,
     KKT_DIVERGED_DTOL = -4,
     KKT_DIVERGED_BREAKDOWN = -5,
-    KKT_DIVERGED_NANORINF = -9
+    KKT_DIVERGED_INDEFINITE_PC = -8,   /* minres: r.Br < 0 */
+    KKT_DIVERGED_NANORINF = -9,
+    KKT_DIVERGED_INDEFINITE_MAT = -10  /* minres: Lanczos r.Br < 0 after the first step */
 };
 
 /* ------------------------------------------------------------------ life cycle */

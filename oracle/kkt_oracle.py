@@ -329,6 +329,96 @@ def fgmres(A, B, b, x, **kw):
     return _gmres_driver(A, B, b, x, flexible=True, right=True, **kw)
 
 
+DIVERGED_INDEFINITE_PC = -8
+DIVERGED_INDEFINITE_MAT = -10
+
+
+def minres(A, B, b, x, *, rtol, atol, divtol, max_it, monitor=None, restart=None,
+           right=False, reduce=None):
+    """Preconditioned MINRES (Paige & Saunders 1975), structured like the classic
+    ``KSPSolve_MINRES`` of PETSc up to 3.18 (``src/ksp/ksp/impls/minres/minres.c``): Lanczos
+    on ``A`` in the ``B`` inner product, one Givens rotation per step, monitored norm
+    ``||B r_0||_2 * prod |s_k|`` (recurrence), ``B`` must be symmetric positive definite.
+
+    Reachable in the reference through ``solver_parameters["linear_solver"] = "minres"``
+    (``preconditioner.py:733``) but never used by it or its tests.  PETSc is
+    not in this image and 3.19+ replaced the implementation (same iterates in exact
+    arithmetic, another residual estimate): parity with PETSc is unpinned; the iterates
+    are pinned against SciPy's independent ``minres`` in ``tests/test_oracle.py``.
+    """
+    haptol = 1.0e-50
+    dot = (lambda u, v: float(np.dot(u, v))) if reduce is None else \
+        (lambda u, v: float(reduce(np.array([np.dot(u, v)]))[0]))
+    res = KSPResult()
+    conv = _ConvergedDefault(rtol, atol, divtol, np.sqrt(dot(B(b), B(b))))
+    n = b.size
+    uold, vold, w, wold = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n)
+    r = b - A(x)
+    z = B(r)
+    nrm = np.sqrt(dot(z, z))
+    dp = dot(r, z)
+    res.rnorm = nrm
+    if dp < haptol and nrm > haptol:
+        res.reason = DIVERGED_INDEFINITE_PC
+        return res
+    res.history.append(nrm)
+    if monitor is not None:
+        monitor(0, nrm)
+    res.reason = conv(nrm)
+    if res.reason:
+        return res
+    beta = np.sqrt(abs(dp))
+    eta = beta
+    v, u = r * (1.0 / beta), z * (1.0 / beta)
+    c = cold = 1.0
+    s = sold = 0.0
+    i = 0
+    while i < max_it:
+        res.its = i + 1
+        r = A(u)                                   # Lanczos
+        alpha = dot(u, r)
+        z = B(r)
+        r -= alpha * v
+        z -= alpha * u
+        r -= beta * vold
+        z -= beta * uold
+        betaold = beta
+        dp = dot(r, z)
+        beta = np.sqrt(abs(dp))
+        coold, cold, soold, sold = cold, c, sold, s    # QR factorisation
+        rho0 = cold * alpha - coold * sold * betaold
+        rho1 = np.sqrt(rho0 * rho0 + beta * beta)
+        rho2 = sold * alpha + coold * cold * betaold
+        rho3 = soold * betaold
+        c, s = rho0 / rho1, beta / rho1
+        woold, wold = wold, w
+        w = u - rho2 * wold
+        w -= rho3 * woold
+        w *= 1.0 / rho1
+        x += (c * eta) * w
+        if dp < haptol:                            # converged or indefinite: true residual
+            nrm = np.sqrt(dot(A(x) - b, A(x) - b))
+        else:
+            nrm *= abs(s)
+        res.rnorm = nrm
+        res.history.append(nrm)
+        if monitor is not None:
+            monitor(i + 1, nrm)
+        res.reason = conv(nrm)
+        if res.reason:
+            break
+        if dp < haptol:
+            res.reason = DIVERGED_INDEFINITE_MAT
+            break
+        eta = -s * eta
+        vold, uold = v, u
+        v, u = r * (1.0 / beta), z * (1.0 / beta)
+        i += 1
+    if not res.reason:
+        res.reason = DIVERGED_ITS
+    return res
+
+
 def chebyshev_jacobi(A, dinv, b, emin, emax, its):
     """``KSPSolve_Chebyshev`` (first kind) with ``PCJACOBI``, zero guess, ``its`` steps.
 
@@ -507,8 +597,10 @@ class OracleSystem:
             res = gmres(A, B, b, u, right=(sp_.get("pc_side", "left") == "right"), **kw)
         elif ksp_type == "fgmres":
             res = fgmres(A, B, b, u, **kw)
+        elif ksp_type == "minres":
+            res = minres(A, B, b, u, **kw)
         else:
-            raise ValueError(f"oracle restates gmres and fgmres only, not {ksp_type}")
+            raise ValueError(f"oracle restates gmres, fgmres and minres only, not {ksp_type}")
         u0, u1 = self.split(u)
         for i in range(n0):
             self.nullspaces[i].lhs_right(u0[i])

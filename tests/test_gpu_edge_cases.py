@@ -163,7 +163,7 @@ def test_argument_errors():
     g = MultiBlockSystem(nx, nx, {(0, 0): A}, {(0, 0): None}, {(0, 0): None}, {(0, 0): A})
     with pytest.raises(ValueError, match="linear_solver"):
         g.solve(np.zeros((1, nx)), np.zeros((1, nx)), np.ones((1, nx)), np.ones((1, nx)),
-                solver_parameters={"linear_solver": "minres", "relative_tolerance": 1e-8,
+                solver_parameters={"linear_solver": "bicg", "relative_tolerance": 1e-8,
                                    "absolute_tolerance": 0.0})
     with pytest.raises(KeyError):      # relative_tolerance is required (preconditioner.py:739)
         g.solve(np.zeros((1, nx)), np.zeros((1, nx)), np.ones((1, nx)), np.ones((1, nx)),

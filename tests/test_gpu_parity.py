@@ -317,3 +317,63 @@ def test_timed_sweep_programs_give_the_preconditioner_result(CN):
     assert np.array_equal(got, ref)
     assert launches.value >= 2 and ms.value > 0.0
     assert phases.value >= 2 * (p["m"] - 1) * 13 and phases.value <= 2 * (p["m"] + 1) * 14
+
+
+# ---- MINRES through the C-ABI ("linear_solver": "minres", preconditioner.py:733)
+def _spd_jacobi(p):
+    d = p["sd"].M.diagonal()
+    tau, beta = p["tau"], p["beta"]
+
+    def pc(u_0, u_1, b_0, b_1):
+        u_0[:] = b_0 / (tau * d)
+        u_1[:] = b_1 / ((tau / beta) * d)
+    return pc
+
+
+@pytest.mark.parametrize("pc_kind", ["identity", "spd"])
+def test_minres_iterates_parity(pc_kind):
+    """Device MINRES against the oracle's restatement of PETSc's classic ``KSPSolve_MINRES``:
+    same residual history (1e-9 relative over the first 60 steps: Lanczos recurrences lose
+    digits at the rate the basis loses orthogonality, as GMRES' left-preconditioned BE
+    iterates do) and the same converged solution."""
+    p = common.heat_problem(n=6, n_t=4, CN=False)
+    osys, gsys = common.oracle_system(p), common.gpu_system(p)
+    m, nx = p["m"], p["sd"].n_dofs
+    b = common.rng_vector(2 * m * nx).reshape(2 * m, nx)
+    b[:, p["nodes"]] = 0.0
+    pc = _spd_jacobi(p) if pc_kind == "spd" else None
+    sp = {"linear_solver": "minres", "relative_tolerance": 1e-11, "absolute_tolerance": 0.0,
+          "maximum_iterations": 6000, "monitor_convergence": False, "divergence limit": 1e12}
+    vo, zo = np.zeros((m, nx)), np.zeros((m, nx))
+    ro = osys.solve(vo, zo, b[:m], b[m:], solver_parameters=sp, pc_fn=pc)
+    vg, zg = np.zeros((m, nx)), np.zeros((m, nx))
+    rg = gsys.solve(vg, zg, b[:m], b[m:], solver_parameters=sp, pc_fn=pc)
+    assert rg.reason == ro.reason == 2
+    k = min(60, len(ro.history), len(rg.history))
+    assert np.allclose(rg.history[:k], ro.history[:k], rtol=1e-9, atol=0.0)
+    assert abs(rg.its - ro.its) <= max(3, ro.its // 50)
+    assert common.rel_err(np.r_[vg.ravel(), zg.ravel()], np.r_[vo.ravel(), zo.ravel()]) < 1e-8
+    assert np.all(vg[:, p["nodes"]] == 0.0)
+
+
+def test_minres_reports_an_indefinite_preconditioner_and_refuses_right_side():
+    p = common.heat_problem(n=6, n_t=4, CN=False)
+    gsys = common.gpu_system(p)
+    m, nx = p["m"], p["sd"].n_dofs
+    b = common.rng_vector(2 * m * nx).reshape(2 * m, nx)
+    b[:, p["nodes"]] = 0.0
+
+    def negative(u_0, u_1, b_0, b_1):
+        u_0[:] = -b_0
+        u_1[:] = -b_1
+    sp = {"linear_solver": "minres", "relative_tolerance": 1e-8, "absolute_tolerance": 0.0,
+          "maximum_iterations": 50, "monitor_convergence": False, "preconditioner": True}
+    r = gsys.solve(np.zeros((m, nx)), np.zeros((m, nx)), b[:m], b[m:], solver_parameters=sp,
+                   pc_fn=negative)
+    assert r.reason == -8 and r.its == 0          # KSP_DIVERGED_INDEFINITE_PC
+    with pytest.raises(RuntimeError, match="Solver failed to converge"):
+        gsys.solve(np.zeros((m, nx)), np.zeros((m, nx)), b[:m], b[m:],
+                   solver_parameters=dict(sp, preconditioner=False), pc_fn=negative)
+    with pytest.raises(Exception, match="left preconditioning"):
+        gsys.solve(np.zeros((m, nx)), np.zeros((m, nx)), b[:m], b[m:],
+                   solver_parameters=dict(sp, pc_side="right"))

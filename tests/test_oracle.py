@@ -118,3 +118,62 @@ def test_BE_iterates_are_ill_conditioned():
     n = min(len(H[0]), len(H[1]), 11)
     drift = np.abs(H[0][:n] - H[1][:n]) / H[0][:n]
     assert drift[:3].max() < 1e-9 and drift.max() > 1e-6
+
+
+# ---- MINRES (reachable through "linear_solver": "minres", never used by the reference)
+def _spd_jacobi(p):
+    """A symmetric positive definite preconditioner for the BE system: Jacobi on
+    ``tau M`` (state rows) and ``(tau / beta) M`` (adjoint rows)."""
+    d = p["sd"].M.diagonal()
+    tau, beta = p["tau"], p["beta"]
+
+    def pc(u_0, u_1, b_0, b_1):
+        u_0[:] = b_0 / (tau * d)
+        u_1[:] = b_1 / ((tau / beta) * d)
+    return pc
+
+
+def test_minres_iterates_match_scipy():
+    """The restated PETSc-classic MINRES against SciPy's independent implementation of
+    Paige & Saunders: same iterates after k steps on the (symmetric) BE system with an SPD
+    preconditioner.  This pins the algorithm; PETSc itself is not available (unpinned)."""
+    p = common.heat_problem(n=6, n_t=4, CN=False)
+    A = global_matrix(p)
+    assert abs(A - A.T).max() < 1e-14
+    osys = common.oracle_system(p)
+    pc = _spd_jacobi(p)
+    b = common.rng_vector(osys.N)
+    for k in range(2 * p["m"]):
+        b[k * p["sd"].n_dofs + p["nodes"]] = 0.0
+
+    def B(v):
+        return osys.pc_apply(pc, v)
+    Bmat = spla.LinearOperator(A.shape, matvec=B, dtype=np.float64)
+    for k in (1, 7, 40):
+        x = np.zeros(osys.N)
+        r = ko.minres(osys.mult, B, b, x, rtol=0.0, atol=0.0, divtol=1e300, max_it=k)
+        xs, _ = spla.minres(A, b, M=Bmat, maxiter=k, rtol=1e-300)
+        assert r.its == k and r.reason == ko.DIVERGED_ITS and len(r.history) == k + 1
+        assert np.abs(x - xs).max() <= 1e-11 * np.abs(xs).max()
+        assert all(b_ <= a_ * (1 + 1e-12) for a_, b_ in zip(r.history, r.history[1:]))
+
+
+def test_minres_solves_the_system_and_flags_an_indefinite_preconditioner():
+    p = common.heat_problem(n=6, n_t=4, CN=False)
+    osys, m, nx = common.oracle_system(p), p["m"], p["sd"].n_dofs
+    b = common.rng_vector(2 * m * nx).reshape(2 * m, nx)
+    b[:, p["nodes"]] = 0.0
+    sp_ = {"linear_solver": "minres", "relative_tolerance": 1e-12, "absolute_tolerance": 0.0,
+           "maximum_iterations": 4000, "monitor_convergence": False}
+    v, z = np.zeros((m, nx)), np.zeros((m, nx))
+    res = osys.solve(v, z, b[:m], b[m:], solver_parameters=sp_, pc_fn=_spd_jacobi(p))
+    assert res.reason == ko.CONVERGED_RTOL
+    exact = spla.spsolve(global_matrix(p).tocsc(), b.ravel())
+    assert common.rel_err(np.concatenate([v.ravel(), z.ravel()]), exact) < 1e-8
+
+    def negative(u_0, u_1, b_0, b_1):
+        u_0[:] = -b_0
+        u_1[:] = -b_1
+    res = osys.solve(np.zeros((m, nx)), np.zeros((m, nx)), b[:m], b[m:],
+                     solver_parameters=dict(sp_, preconditioner=True), pc_fn=negative)
+    assert res.reason == ko.DIVERGED_INDEFINITE_PC and res.its == 0
