@@ -333,9 +333,12 @@ def _spd_jacobi(p):
 @pytest.mark.parametrize("pc_kind", ["identity", "spd"])
 def test_minres_iterates_parity(pc_kind):
     """Device MINRES against the oracle's restatement of PETSc's classic ``KSPSolve_MINRES``:
-    same residual history (1e-9 relative over the first 60 steps: Lanczos recurrences lose
-    digits at the rate the basis loses orthogonality, as GMRES' left-preconditioned BE
-    iterates do) and the same converged solution."""
+    same residual history over the first 25 steps (1e-9 relative) and the same converged
+    solution.  Later steps are not compared entry by entry: the Lanczos recurrence amplifies
+    the order of summation in the inner products -- the oracle run against itself with the
+    dot products summed backwards agrees to 2e-13 after 30 steps, 1e-5 after 60 and differs
+    by 2 % in the iteration count (1 115 / 1 137 with the identity, 131 / 130 with the SPD
+    preconditioner) while the solutions agree to 2e-12."""
     p = common.heat_problem(n=6, n_t=4, CN=False)
     osys, gsys = common.oracle_system(p), common.gpu_system(p)
     m, nx = p["m"], p["sd"].n_dofs
@@ -349,9 +352,9 @@ def test_minres_iterates_parity(pc_kind):
     vg, zg = np.zeros((m, nx)), np.zeros((m, nx))
     rg = gsys.solve(vg, zg, b[:m], b[m:], solver_parameters=sp, pc_fn=pc)
     assert rg.reason == ro.reason == 2
-    k = min(60, len(ro.history), len(rg.history))
+    k = min(25, len(ro.history), len(rg.history))
     assert np.allclose(rg.history[:k], ro.history[:k], rtol=1e-9, atol=0.0)
-    assert abs(rg.its - ro.its) <= max(3, ro.its // 50)
+    assert abs(rg.its - ro.its) <= max(3, ro.its // 20)
     assert common.rel_err(np.r_[vg.ravel(), zg.ravel()], np.r_[vo.ravel(), zo.ravel()]) < 1e-8
     assert np.all(vg[:, p["nodes"]] == 0.0)
 
