@@ -48,6 +48,23 @@ def measured_traffic(workload):
     return best
 
 
+def measured_sweep_traffic(workload, preconditioner, phases_per_launch):
+    """HBM-side bytes per launch of the sweep program from the committed --pmc passes
+    (profiles/*/traffic_pc_row_program_g.json) for this workload and preconditioner."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*",
+                                           "traffic_pc_row_program_g.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if (d.get("workload") == workload and d.get("preconditioner") == preconditioner
+                and d.get("phases_per_launch") == phases_per_launch):
+            best = d.get("hbm_bytes_per_launch")
+    return best
+
+
 def build_problem(args):
     from control_amd.blocks import instationary_blocks
     from control_amd.fem import unit_cube_p1, unit_square_p1
@@ -419,6 +436,10 @@ def main():
                     " CSR formula; index arrays are shared on the device"},
     }
     if sweeps is not None:
+        # HBM-side bytes of one application (all sweep launches) from the committed PMC passes
+        per_launch = measured_sweep_traffic(workload, out["config"]["preconditioner"],
+                                            sweeps["phases"] // sweeps["launches"])
+        sweeps["traffic"] = None if per_launch is None else per_launch * sweeps["launches"]
         out["roofline_sweeps"] = sweeps
     if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (contract)
         out["cpu_baseline"] = cpu_baseline(p, args)
