@@ -1,4 +1,4 @@
-"""Time-sharded path on one GPU box: 2 and 3 ranks (processes) share GPU 0, hand-offs go
+"""Time-sharded path on one GPU box: 2, 3 and 5 ranks (processes; 5 leaves a one-level shard) share GPU 0, hand-offs go
 through the host-staged callback transport.  The RCCL transport differs only in
 ``csrc/comm.cpp``'s RcclComm methods; halo pattern, pipelined sweeps and reductions are
 the code exercised here."""
@@ -43,7 +43,7 @@ def launch(world, CN, ksp):
     return res
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 5])
 @pytest.mark.parametrize("CN", [False, True])
 def test_sharded_matches_oracle(world, CN):
     res = launch(world, CN, "fgmres")
