@@ -553,9 +553,23 @@ __global__ __launch_bounds__(512) void pc_row_program(const RowOp *__restrict__ 
     const Bases B{{nullptr, nullptr, nullptr, nullptr}};
     bool dead = false;   // a spin timed out: stop waiting, run to the end, results invalid
     unsigned long long dnext = load_desc_words(ops);
+#ifdef KKT_STAMPS
+    // diagnostic build: per-workgroup cycle sums of the stages of a phase (scripts/prog_stamps.py)
+    unsigned long long *sdbg = reinterpret_cast<unsigned long long *>(err + 64) + blockIdx.x * 16;
+    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#define KKT_FSTAGE(i)                                                  \
+    do {                                                               \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime(); \
+        if (threadIdx.x == 0) sdbg[8 + (i)] += t_now - t_prev;         \
+        t_prev = t_now;                                                \
+    } while (0)
+#else
+#define KKT_FSTAGE(i)
+#endif
     for (int ph = 0; ph < nphases; ++ph) {
         const unsigned long long desc = dnext;
         if (ph + 1 < nphases) dnext = load_desc_words(ops + ph + 1);   // lands during this phase
+        KKT_FSTAGE(0);   // loop top, descriptor prefetch issue
         if (ph > 0) {
             if (wave == 0) {
                 const int jj = d.x + lane;
@@ -576,16 +590,24 @@ __global__ __launch_bounds__(512) void pc_row_program(const RowOp *__restrict__ 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __syncthreads();
         }
+        KKT_FSTAGE(1);   // wait for the neighbours' counters + workgroup barrier
         const RowOp op = unpack_desc_head(desc);
         rowops_body<R, false, WFIX, true>(
             op, [&](int t) { return unpack_desc_term(desc, t); }, B, s);
+        KKT_FSTAGE(2);   // loads, fma chain, store issue
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        KKT_FSTAGE(3);   // store drain
         __syncthreads();
         if (threadIdx.x == 0)
             __hip_atomic_store(flags + (size_t)j * FLAG_STRIDE, (unsigned)(ph + 1), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
+        KKT_FSTAGE(4);   // workgroup barrier + counter store
+#ifdef KKT_STAMPS
+        if (threadIdx.x == 0) sdbg[2] += 1;
+#endif
     }
 }
+#undef KKT_FSTAGE
 
 // Data-flow form for structures without a small fixed width (P2 / Q2 / 3-D P1): the phases
 // of pc_row_program with the hand-off of pc_row_program_g -- gathers poll tagged granules in
