@@ -115,9 +115,33 @@ __device__ __forceinline__ void load_cols(gci_p p, int (&c)[R]) {
 // vector a phase produces also travels as {tag, 32 value bits} granules, two per row.
 struct NoGran {
     static constexpr bool on = false;
+    static constexpr bool hoist = false;
+};
+// Counter form of the persistent programs, slices without a compile-time width.  A phase of
+// such a program was a chain of dependent round trips: slice offset -> row numbers -> row
+// mask -> (sc1) own-row operands -> column indices -> (sc1) gathers, chunk by chunk.  What does
+// not change while consecutive phases work on the same structure -- slice offset and width,
+// row numbers, row mask, diagonal -- is kept in registers across phases, and the first chunk of
+// column indices and matrix values of the phase is fetched before the wave waits for its
+// neighbours, so that after the wait the own-row operands and the first gathers go out
+// back to back.
+constexpr int HOIST_KC = 12;
+template <int R>
+struct Hoist {
+    static constexpr bool on = false;
+    static constexpr bool hoist = true;
+    const void *key_slice, *key_perm, *key_mask, *key_dinv;   // what the cache was read for
+    int key_uw, key_nrows;
+    int off0, w;
+    int row[R];
+    bool masked[R];
+    double dinv[R];
+    int c[HOIST_KC][R];                 // chunk 0 of term 0 of the phase being prepared
+    double v[HOIST_KC][R];
 };
 struct Gran {
     static constexpr bool on = true;
+    static constexpr bool hoist = false;
     const unsigned long long *xg;   // granules written by the previous phase
     unsigned long long *yg;         // granules this phase writes
     unsigned ep_in, ep_out;         // tags to expect (0: gather plain memory) / to publish
@@ -197,7 +221,48 @@ __device__ __forceinline__ void accumulate_generic(const RowOp &op, const TermFn
     constexpr int C = 64 * R;
     const gci_p colp = (gci_p)op.col + base;
     const int nterms = op.nterms;
-    if constexpr (COH) {
+    if constexpr (GranT::hoist) {
+        // as the COH path below, with the chunk registers owned by the caller: chunk 0 of
+        // term 0 was loaded by hoist_prepare before the wave waited for its neighbours
+        static_assert(COH, "hoisted operands belong to the persistent programs");
+        constexpr int KC = HOIST_KC;
+        for (int t = 0; t < (w > 0 ? nterms : 0); ++t) {
+            const SpmvTerm tm = terms(t);
+            const gcd_p vp = (gcd_p)tm.vals + base;
+            const gcd_p x = resolve(tm.x, bases);
+            if (t > 0) {
+#pragma unroll
+                for (int k = 0; k < KC; ++k)
+                    load_cols<R>(colp + (size_t)(k < w ? k : w - 1) * C, gran.c[k]);
+            }
+            for (int k0 = 0; k0 < w; k0 += KC) {
+                double xv[KC][R];
+                if (t > 0 || k0 > 0) {
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) {
+                        const int kk = k0 + k < w ? k0 + k : w - 1;
+                        load_vals<R, NT>(vp + (size_t)kk * C, gran.v[k]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < KC; ++k)
+#pragma unroll
+                    for (int q = 0; q < R; ++q) xv[k][q] = ldv<COH>(x + gran.c[k][q]);
+                if (k0 + KC < w) {
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) {
+                        const int kk = k0 + KC + k < w ? k0 + KC + k : w - 1;
+                        load_cols<R>(colp + (size_t)kk * C, gran.c[k]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < KC; ++k)
+#pragma unroll
+                    for (int q = 0; q < R; ++q)
+                        acc[q] = __builtin_fma(k0 + k < w ? gran.v[k][q] : 0.0, xv[k][q], acc[q]);
+            }
+        }
+    } else if constexpr (COH) {
         // Persistent programs are latency-bound: a phase is a chain of dependent round trips
         // (indices -> gathers through L2 -> fma).  Whole chunks of KC slots are in flight at
         // once and the next chunk's indices travel with the current chunk's gathers; slots
@@ -307,7 +372,10 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const TermFn &terms
     if (s >= op.nslices) return;
     constexpr int C = 64 * R;
     int off0, w;
-    if constexpr (WFIX > 0) {
+    if constexpr (GranT::hoist) {
+        off0 = gran.off0;
+        w = gran.w;
+    } else if constexpr (WFIX > 0) {
         w = WFIX;
         off0 = s * WFIX;
     } else if (op.uniform_w >= 0) {   // same width everywhere: no slice_off round trip
@@ -322,7 +390,10 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const TermFn &terms
     const int nrows = op.nrows;
     // row-sorted structures (SELL-C-sigma): the row stored at a position comes from perm
     int row[R];
-    {
+    if constexpr (GranT::hoist) {
+#pragma unroll
+        for (int q = 0; q < R; ++q) row[q] = gran.row[q];
+    } else {
         const gci_p perm = (gci_p)op.perm;
 #pragma unroll
         for (int q = 0; q < R; ++q) {
@@ -352,11 +423,16 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const TermFn &terms
     for (int q = 0; q < R; ++q) {
         const int r = row[q];
         const bool in = r >= 0;
-        masked[q] = in && rowmask != nullptr && rowmask[r] != 0;
+        if constexpr (GranT::hoist) {
+            masked[q] = gran.masked[q];
+            e3[q] = pd ? gran.dinv[q] : 0.0;
+        } else {
+            masked[q] = in && rowmask != nullptr && rowmask[r] != 0;
+            e3[q] = (in && pd) ? pd[r] : 0.0;   // dinv: never written inside a launch
+        }
         e0[q] = (in && pa) ? ldv<COH>(pa + r) : 0.0;
         e1[q] = (in && pb) ? ldv<COH>(pb + r) : 0.0;
         e2[q] = (in && pc) ? ldv<COH>(pc + r) : 0.0;
-        e3[q] = (in && pd) ? pd[r] : 0.0;   // dinv: never written inside a launch
     }
 
     double acc[R];
@@ -540,6 +616,64 @@ __device__ __forceinline__ SpmvTerm unpack_desc_term(unsigned long long desc, in
     return tm;
 }
 
+// Everything of phase `op` that can be read before the neighbours have finished the
+// previous phase (see Hoist).  Matrix structure, values, row mask and diagonal are never
+// written inside a launch.
+template <int R>
+__device__ __forceinline__ void hoist_prepare(Hoist<R> &h, const RowOp &op, const SpmvTerm &t0,
+                                              int s) {
+    constexpr int C = 64 * R;
+    const int lane = threadIdx.x & 63;
+    if (s >= op.nslices) return;
+    if (h.key_slice != (const void *)op.slice_off || h.key_perm != (const void *)op.perm ||
+        h.key_uw != op.uniform_w || h.key_nrows != op.nrows) {
+        h.key_slice = (const void *)op.slice_off;
+        h.key_perm = (const void *)op.perm;
+        h.key_uw = op.uniform_w;
+        h.key_nrows = op.nrows;
+        h.key_mask = h.key_dinv = (const void *)(uintptr_t)1;   // rows changed: re-read below
+        if (op.uniform_w >= 0) {
+            h.w = op.uniform_w;
+            h.off0 = s * h.w;
+        } else {
+            h.off0 = ((gci_p)op.slice_off)[s];
+            h.w = ((gci_p)op.slice_off)[s + 1] - h.off0;
+        }
+        const gci_p perm = (gci_p)op.perm;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int pos = s * C + lane + 64 * q;
+            h.row[q] = perm ? perm[pos] : (pos < op.nrows ? pos : -1);
+        }
+    }
+    if (h.key_mask != (const void *)op.rowmask) {
+        h.key_mask = (const void *)op.rowmask;
+        const gcb_p rowmask = (gcb_p)op.rowmask;
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+            h.masked[q] = h.row[q] >= 0 && rowmask != nullptr && rowmask[h.row[q]] != 0;
+    }
+    if (h.key_dinv != (const void *)op.dinv) {
+        h.key_dinv = (const void *)op.dinv;
+        const gcd_p dinv = (gcd_p)op.dinv;
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+            h.dinv[q] = (h.row[q] >= 0 && dinv != nullptr) ? dinv[h.row[q]] : 0.0;
+    }
+    if (op.nterms > 0 && h.w > 0) {
+        const size_t base = (size_t)h.off0 * C + (size_t)lane * R;
+        const gci_p colp = (gci_p)op.col + base;
+        const gcd_p vp = (gcd_p)t0.vals + base;
+        const int w = h.w;
+#pragma unroll
+        for (int k = 0; k < HOIST_KC; ++k) {
+            const size_t kk = (size_t)(k < w ? k : w - 1) * C;
+            load_cols<R>(colp + kk, h.c[k]);
+            load_vals<R, false>(vp + kk, h.v[k]);
+        }
+    }
+}
+
 template <int R, int WFIX>
 __global__ __launch_bounds__(512) void pc_row_program(const RowOp *__restrict__ ops, int nphases,
                                                        const int2 *__restrict__ dep,
@@ -566,10 +700,17 @@ __global__ __launch_bounds__(512) void pc_row_program(const RowOp *__restrict__ 
 #else
 #define KKT_FSTAGE(i)
 #endif
+    Hoist<R> hoist;
+    hoist.key_slice = hoist.key_perm = hoist.key_mask = hoist.key_dinv =
+        (const void *)(uintptr_t)1;   // matches no structure
+    hoist.key_uw = hoist.key_nrows = -2;
+    hoist.off0 = hoist.w = 0;
     for (int ph = 0; ph < nphases; ++ph) {
         const unsigned long long desc = dnext;
         if (ph + 1 < nphases) dnext = load_desc_words(ops + ph + 1);   // lands during this phase
-        KKT_FSTAGE(0);   // loop top, descriptor prefetch issue
+        const RowOp op = unpack_desc_head(desc);
+        if constexpr (WFIX == 0) hoist_prepare<R>(hoist, op, unpack_desc_term(desc, 0), s);
+        KKT_FSTAGE(0);   // loop top: descriptor, cached structure, first chunk issued
         if (ph > 0) {
             if (wave == 0) {
                 const int jj = d.x + lane;
@@ -591,9 +732,12 @@ __global__ __launch_bounds__(512) void pc_row_program(const RowOp *__restrict__ 
             __syncthreads();
         }
         KKT_FSTAGE(1);   // wait for the neighbours' counters + workgroup barrier
-        const RowOp op = unpack_desc_head(desc);
-        rowops_body<R, false, WFIX, true>(
-            op, [&](int t) { return unpack_desc_term(desc, t); }, B, s);
+        if constexpr (WFIX == 0)
+            rowops_body<R, false, WFIX, true>(
+                op, [&](int t) { return unpack_desc_term(desc, t); }, B, s, hoist);
+        else
+            rowops_body<R, false, WFIX, true>(
+                op, [&](int t) { return unpack_desc_term(desc, t); }, B, s);
         KKT_FSTAGE(2);   // loads, fma chain, store issue
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         KKT_FSTAGE(3);   // store drain
