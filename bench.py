@@ -295,10 +295,13 @@ def main():
     # KKT_DEVICE pins every rank to one GPU (rehearsal of the N > 1 path on a one-GPU box,
     # with KKT_TRANSPORT=gloo); production: one GPU per local rank
     device = int(os.environ.get("KKT_DEVICE", local_rank))
+    t_setup = time.perf_counter()
     gsys = common.gpu_system(p, device=device, comm=comm)
     lib, h = gsys._lib, gsys.handle
     gpc = common.gpu_pc(p, p["mass"], p["schur"])
     gsys._set_pc(gpc)
+    gsys._ck(lib.kkt_sync(h))
+    t_setup = time.perf_counter() - t_setup     # CSR -> device storage + preconditioner build
     info = gsys.info()
     n_local = info["n_local"]
 
@@ -421,7 +424,7 @@ def main():
                                f"Schur Chebyshev {p['schur']} (its, emin, emax)"),
             "parallelism": f"time-block rows over {world} GPU(s)",
             "transport": (os.environ.get("KKT_TRANSPORT", "rccl") if world > 1 else "none"),
-            "pc_apply_ms": pc_ms, "kkt_apply_ms": spmv_ms,
+            "pc_apply_ms": pc_ms, "kkt_apply_ms": spmv_ms, "setup_s": t_setup,
             "time_to_solution": tts},
         "roofline": {
             "kernel": "kkt_spmv_rows (fused block-row SpMV of the KKT operator)",
