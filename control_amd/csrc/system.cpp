@@ -107,11 +107,25 @@ void System::set_shard(int rank_, int world_) {
     n0_loc = n1_loc = hi - lo;
 }
 
+// Fingerprint of an index array (a filter in front of the memcmp in find_or_add_pattern).
+// FNV-1a over 8-byte words in four independent lanes: a byte-serial FNV spent 2.5 ms per
+// 2 MB block on its multiply chain -- 0.9 s of the 1.06 s cfg 2 took to set up.
 static uint64_t fnv1a(const void *data, size_t bytes, uint64_t h) {
+    constexpr uint64_t prime = 1099511628211ull;
     const unsigned char *p = static_cast<const unsigned char *>(data);
-    for (size_t i = 0; i < bytes; ++i) {
+    uint64_t lane[4] = {h, h ^ 0x9e3779b97f4a7c15ull, h ^ 0xc2b2ae3d27d4eb4full,
+                        h ^ 0x165667b19e3779f9ull};
+    size_t i = 0;
+    for (; i + 32 <= bytes; i += 32) {
+        uint64_t w[4];
+        std::memcpy(w, p + i, 32);
+        for (int k = 0; k < 4; ++k) lane[k] = (lane[k] ^ w[k]) * prime;
+    }
+    h = lane[0];
+    for (int k = 1; k < 4; ++k) h = (h ^ (lane[k] >> 29) ^ lane[k]) * prime;
+    for (; i < bytes; ++i) {
         h ^= p[i];
-        h *= 1099511628211ull;
+        h *= prime;
     }
     return h;
 }

@@ -228,7 +228,7 @@ class MultiBlockSystem:
         self._n1_loc = self._hi - self._lo if self._sharded else n_blocks_11
 
         share_ids = {}
-        self._structure = {}     # (quadrant, i, j) -> (nnz, hash of the index arrays)
+        self._structure = {}     # (quadrant, i, j) -> [nnz, hash of the index array or None, the array]
         for q, blk in ((Q00, block_00), (Q01, block_01), (Q10, block_10), (Q11, block_11)):
             for (i, j), A in blk.items():                      # dict order = apply order
                 if A is None:
@@ -241,7 +241,7 @@ class MultiBlockSystem:
                 # the same Python object given for several (i, j) shares device storage
                 sid = share_ids.setdefault(id(A), len(share_ids))
                 # the index array is kept referenced, so its address identifies it for good
-                self._structure[(q, i, j)] = (len(data), hash(indices.tobytes()), indices)
+                self._structure[(q, i, j)] = [len(data), None, indices]   # hash: on first need
                 self._ck(self._lib.kkt_add_block(
                     self._h, q, i, j, nrows, ncols,
                     indptr.ctypes.data_as(_lib.c_i32p), indices.ctypes.data_as(_lib.c_i32p),
@@ -296,8 +296,11 @@ class MultiBlockSystem:
         _, indices, data = _as_csr(A)
         ref = self._structure.get((quadrant, i, j))
         # same index buffer as at construction (block sums share it): nothing to compare
-        same = ref is not None and ref[0] == len(data) and (
-            ref[2].ctypes.data == indices.ctypes.data or ref[1] == hash(indices.tobytes()))
+        same = ref is not None and ref[0] == len(data)
+        if same and ref[2].ctypes.data != indices.ctypes.data:
+            if ref[1] is None:
+                ref[1] = hash(ref[2].tobytes())
+            same = ref[1] == hash(indices.tobytes())
         if not same:
             raise ValueError(f"block ({quadrant}; {i}, {j}): the new matrix does not have the "
                              "stored sparsity structure")
