@@ -65,6 +65,33 @@ class SpatialDiscretisation:
         return _assemble_like(Me, self.cells, self.cells, self.M.shape)
 
 
+def _p1_convection(self, wind) -> sp.csr_matrix:
+    """``inner(dot(grad(trial), wind), test) * dx`` for P1 triangles: ``wind(X) -> (n, 2)`` is
+    evaluated at the points of Radon's 7-point rule (degree 5); same structure as ``M``."""
+    if self.cells is None:
+        raise NotImplementedError("convection needs a P1 triangle discretisation")
+    s15 = np.sqrt(15.0)
+    a1, a2 = (6.0 - s15) / 21.0, (6.0 + s15) / 21.0
+    w1, w2 = (155.0 - s15) / 1200.0, (155.0 + s15) / 1200.0
+    lam = np.array([[1 / 3, 1 / 3, 1 / 3],
+                    [a1, a1, 1 - 2 * a1], [a1, 1 - 2 * a1, a1], [1 - 2 * a1, a1, a1],
+                    [a2, a2, 1 - 2 * a2], [a2, 1 - 2 * a2, a2], [1 - 2 * a2, a2, a2]])
+    wq = np.array([9.0 / 40.0, w1, w1, w1, w2, w2, w2])
+    X = self.coords[self.cells]                                   # (nc, 3, 2)
+    A = np.concatenate([np.ones((len(X), 3, 1)), X], axis=2)
+    grads = np.transpose(np.linalg.inv(A)[:, 1:, :], (0, 2, 1))   # (nc, 3, 2): grad of phi_b
+    d1, d2 = X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]
+    area = 0.5 * np.abs(d1[:, 0] * d2[:, 1] - d1[:, 1] * d2[:, 0])
+    Xq = np.einsum("qa,cad->cqd", lam, X)                         # quadrature points
+    W = np.asarray(wind(Xq.reshape(-1, 2))).reshape(len(X), len(wq), 2)
+    wg = np.einsum("cqd,cbd->cqb", W, grads)                      # wind . grad(phi_b)
+    Ce = np.einsum("cq,qa,cqb->cab", wq[None, :] * area[:, None], lam, wg)
+    return _assemble_like(Ce, self.cells, self.cells, self.M.shape)
+
+
+SpatialDiscretisation.convection = _p1_convection
+
+
 def _canonical_csr(A: sp.spmatrix) -> sp.csr_matrix:
     A = sp.csr_matrix(A)
     A.sum_duplicates()

@@ -226,6 +226,58 @@ def mms_heat_control(N, CN, n_t=10):
     return ctl, disc, ref_v, ref_zeta
 
 
+def mms_convection_diffusion_control(N, CN, n_t=10):
+    """``test/test_control.py:2297-2440``: the heat problem above with the time-dependent,
+    divergence-free wind ``cos(pi t / 2) (2 y (1 - x^2), -2 x (1 - y^2))`` (coordinates shifted
+    to the centre of ``[0, 2]^2``) in the state equation: ``forward_form = grad-grad +
+    (wind . grad trial) test``, a non-symmetric operator that differs on every time level.
+    The exact solution is the heat test's (linear in time).  The reference's CN variant
+    (``2675-2860``) uses an exponential-in-time solution; with ``CN=True`` this helper keeps
+    the BE data (still a manufactured solution of the same equations)."""
+    from control_amd.control import Instationary
+    from control_amd.fem import rectangle_p1
+    disc = rectangle_p1(N, N, 2.0, 2.0)
+    beta, t_f = 1.0, 2.0
+    hp = 0.5 * np.pi
+
+    def c(X):
+        return np.cos(hp * (X[:, 0] - 1.0)) * np.cos(hp * (X[:, 1] - 1.0))
+
+    def grad_c(X):
+        x, y = X[:, 0] - 1.0, X[:, 1] - 1.0
+        return np.stack([-hp * np.sin(hp * x) * np.cos(hp * y),
+                         -hp * np.cos(hp * x) * np.sin(hp * y)], 1)
+
+    def wind(X, t):
+        x, y = X[:, 0] - 1.0, X[:, 1] - 1.0
+        return np.cos(hp * t) * np.stack([2.0 * y * (1.0 - x * x), -2.0 * x * (1.0 - y * y)], 1)
+
+    def ref_v(X, t):
+        return 1.0 + (t_f - t) * c(X)
+
+    def ref_zeta(X, t):
+        return (t_f - t) * c(X)
+
+    def w_grad_c(X, t):
+        return np.einsum("nd,nd->n", wind(X, t), grad_c(X))
+
+    def desired_state(X, t):      # zeta_space - lapl(zeta) - wind . grad(zeta) + v
+        return (c(X) + 0.5 * np.pi**2 * (t_f - t) * c(X) - (t_f - t) * w_grad_c(X, t)
+                + ref_v(X, t))
+
+    def force_f(X, t):            # - v_space - lapl(v) + wind . grad(v) - zeta / beta
+        return (-c(X) + 0.5 * np.pi**2 * (t_f - t) * c(X) + (t_f - t) * w_grad_c(X, t)
+                - ref_zeta(X, t) / beta)
+
+    def forward(v_old, t):
+        return disc.K + disc.convection(lambda Xq: wind(Xq, t))
+
+    ctl = Instationary(disc, forward, desired_state=desired_state, force_f=force_f, beta=beta,
+                       CN=CN, n_t=n_t, initial_condition=lambda X: ref_v(X, 0.0),
+                       time_interval=(0.0, t_f), bcs_v=lambda Xb, t: np.ones(len(Xb)))
+    return ctl, disc, ref_v, ref_zeta
+
+
 MMS_SOLVER_PARAMETERS = {"linear_solver": "fgmres", "fgmres_restart": 10,
                          "maximum_iterations": 200, "relative_tolerance": 1.0e-10,
                          "absolute_tolerance": 1.0e-10, "monitor_convergence": False}

@@ -49,6 +49,47 @@ def test_mms_heat_control_on_the_gpu(CN):
 
 
 @pytest.mark.parametrize("CN", [False, True])
+def test_mms_convection_diffusion_control_orders_with_the_oracle(CN):
+    """``test/test_control.py:2297-2493`` (BE; the CN run keeps the BE data, see the helper):
+    a non-symmetric forward operator that changes with the time level.  P1 orders asserted
+    (the reference prints them)."""
+    errs = []
+    for N in (4, 8, 16):
+        ctl, disc, ref_v, ref_zeta = common.mms_convection_diffusion_control(N, CN)
+        ksp = ctl.linear_solve(solver_parameters=common.MMS_SOLVER_PARAMETERS,
+                               lambda_v_bounds=(0.5, 2.0), backend=common.OracleBackend())
+        assert ksp.reason > 0
+        assert np.all(ctl._v[:, disc.boundary] == 1.0)
+        assert np.all(ctl._zeta[:, disc.boundary] == 0.0)
+        errs.append(common.mms_errors(ctl, disc, ref_v, ref_zeta))
+    errs = np.array(errs)
+    orders = np.log(errs[:-1] / errs[1:]) / np.log(2.0)
+    # measured 1.77 / 1.81 (4 -> 8) and 1.94 / 1.95 (8 -> 16), BE and CN alike
+    assert orders[0].min() > 1.7 and orders[1].min() > 1.9, (errs, orders)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("CN", [False, True])
+def test_mms_convection_diffusion_control_on_the_gpu(CN):
+    """Non-symmetric, level-dependent blocks through the C-ABI: the transposed blocks of the
+    adjoint rows and the backward sweep of the preconditioner are genuinely different
+    matrices here."""
+    from control_amd.control import GpuBackend
+    N = 16
+    ctl, disc, ref_v, ref_zeta = common.mms_convection_diffusion_control(N, CN)
+    ksp = ctl.linear_solve(solver_parameters=common.MMS_SOLVER_PARAMETERS,
+                           lambda_v_bounds=(0.5, 2.0), backend=GpuBackend(schur=(30, 0.02, 2.2)))
+    assert ksp.getConvergedReason() > 0
+    ref, *_ = common.mms_convection_diffusion_control(N, CN)
+    ref.linear_solve(solver_parameters=common.MMS_SOLVER_PARAMETERS,
+                     lambda_v_bounds=(0.5, 2.0), backend=common.OracleBackend())
+    assert np.abs(ctl._v - ref._v).max() < 1e-7
+    assert np.abs(ctl._zeta - ref._zeta).max() < 1e-7
+    ev, ez = common.mms_errors(ctl, disc, ref_v, ref_zeta)
+    assert ev < 2e-2 and ez < 2e-2
+
+
+@pytest.mark.parametrize("CN", [False, True])
 def test_instationary_stokes_control_with_exact_sol_oracle(CN):
     """``test/test_control.py:3045-3172`` / ``3175-3302`` (the reference runs these without
     asserting anything): the driver's right-hand sides and Dirichlet lifting reproduce the
@@ -157,6 +198,95 @@ def test_stationary_picard_loop_with_the_oracle():
     r1 = -(D @ ctl._v) + disc.M @ ctl._zeta
     r0[disc.boundary] = r1[disc.boundary] = 0.0
     assert max(np.abs(r0).max(), np.abs(r1).max()) < 1.0e-9
+    # the reference's own check (test_control.py:766-860): against the minimiser of the reduced
+    # functional, 1e-8 on the state and 1e-6 on the control
+    _, _, _, forward, jacobian = _gauss_newton_reference_problem()
+    inner, Mi, u, m = _reduced_nonlinear_optimum(disc, v_d, forward, jacobian)
+    assert np.sqrt(abs((ctl._v - u)[inner] @ (Mi @ (ctl._v - u)[inner]))) < 1.0e-8
+    assert np.sqrt(abs((ctl._zeta[inner] - m) @ (Mi @ (ctl._zeta[inner] - m)))) < 1.0e-6
+
+
+def _gauss_newton_reference_problem():
+    """``test/test_control.py:866-930``: the forward form is the non-linear residual
+    ``grad v . grad w + (2 + 0.5 v^2) v w``; with ``set_Gauss_Newton()`` the operator is its
+    derivative ``grad-grad + (2 + 1.5 v^2) mass`` (``ufl.derivative``, ``control.py:314-320``)."""
+    from control_amd.control import Stationary
+    from control_amd.fem import unit_square_p1
+    disc = unit_square_p1(8)
+
+    def v_d(X):
+        return np.sin(np.pi * X[:, 0]) * np.sin(np.pi * X[:, 1]) * np.exp(X[:, 0] + X[:, 1])
+
+    def weighted(v, a, b):
+        return disc.weighted_mass(lambda lam, cells: a + b * (v[cells] @ lam.T) ** 2)
+
+    def forward(v):
+        return disc.K + weighted(v, 2.0, 0.5)
+
+    def jacobian(v):
+        return disc.K + weighted(v, 2.0, 1.5)
+    ctl = Stationary(disc, forward, desired_state=v_d, beta=1.0, forward_jacobian=jacobian)
+    return ctl, disc, v_d, forward, jacobian
+
+
+def _reduced_nonlinear_optimum(disc, v_d, forward, jacobian):
+    """The reference's independent answer (``test_control.py:945-1014``): L-BFGS-B on the reduced
+    functional ``|u(m) - r|^2 + beta^2 |m|^2`` (beta = 1) with ``u(m)`` from a Newton solve of
+    ``-lapl u + (2 + 0.5 u^2) u = m``; the gradient comes from the adjoint equation instead of
+    tlm_adjoint."""
+    import scipy.optimize as so
+    import scipy.sparse.linalg as spla
+    inner = np.setdiff1d(np.arange(disc.n_dofs), disc.boundary)
+    Mi = disc.M.tocsr()[inner][:, inner]
+    r = v_d(disc.coords)
+
+    def state(m_i):
+        u = np.zeros(disc.n_dofs)
+        for _ in range(50):
+            res = (forward(u) @ u)[inner] - Mi @ m_i
+            du = spla.spsolve(jacobian(u).tocsr()[inner][:, inner].tocsc(), -res)
+            u[inner] += du
+            if np.abs(du).max() < 1e-14:
+                break
+        return u
+
+    def functional(m_i):
+        u = state(m_i)
+        e = (u - r)[inner]
+        lam = spla.spsolve(jacobian(u).tocsr()[inner][:, inner].T.tocsc(), -2.0 * (Mi @ e))
+        return e @ (Mi @ e) + m_i @ (Mi @ m_i), 2.0 * (Mi @ m_i) - Mi @ lam
+    res = so.minimize(functional, np.zeros(len(inner)), jac=True, method="L-BFGS-B",
+                      options={"ftol": 0.0, "gtol": 1.0e-12, "maxiter": 2000})
+    return inner, Mi, state(res.x), res.x
+
+
+def _check_gauss_newton_against_the_reduced_problem(backend):
+    ctl, disc, v_d, forward, jacobian = _gauss_newton_reference_problem()
+    ctl.set_Gauss_Newton()
+    norms = ctl.non_linear_solve(solver_parameters=KAT_SP, lambda_v_bounds=(0.5, 2.0),
+                                 max_non_linear_iter=100, relative_non_linear_tol=1.0e-8,
+                                 backend=backend)
+    assert norms[-1] <= 1.0e-8 * norms[0]
+    inner, Mi, u, m = _reduced_nonlinear_optimum(disc, v_d, forward, jacobian)
+
+    def l2(e):
+        return np.sqrt(abs(e @ (Mi @ e)))
+    assert l2((ctl._v - u)[inner]) < 1.0e-8            # test_control.py:1019
+    assert l2(ctl._zeta[inner] / 1.0 - m) < 1.0e-6     # test_control.py:1024 (control = zeta / beta)
+    return ctl
+
+
+def test_GN_stationary_non_linear_control_with_reference_sol():
+    """``test/test_control.py:866-1024`` restated for P1 (the reference also runs P2 and P3):
+    Gauss-Newton on the non-linear reaction problem lands on the minimiser of the reduced
+    functional, same bars (1e-8 state, 1e-6 control)."""
+    _check_gauss_newton_against_the_reduced_problem(common.OracleBackend(schur=(40, 0.02, 2.2)))
+
+
+@pytest.mark.gpu
+def test_GN_stationary_non_linear_control_with_reference_sol_on_the_gpu():
+    from control_amd.control import GpuBackend
+    _check_gauss_newton_against_the_reduced_problem(GpuBackend(schur=(40, 0.02, 2.2)))
 
 
 @pytest.mark.gpu
