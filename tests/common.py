@@ -226,6 +226,38 @@ def mms_heat_control(N, CN, n_t=10):
     return ctl, disc, ref_v, ref_zeta
 
 
+def mms_heat_control_in_time(N, CN, n_t):
+    """``test/test_control.py:1829-1980`` (BE) / ``2140-2294`` (CN): heat control with an exact
+    solution that is exponential in time -- ``zeta = (e^T - e^t) c(x)``, ``v = 1 + (c_1 +
+    c_2(t)) c(x)``, ``f = 0`` -- so that the time discretisation error is what is measured
+    (BE first order, CN second order).  The reference runs ``N = 250``; the spatial error of
+    the meshes used here is below the time error of the coarse time grids compared."""
+    from control_amd.control import Instationary
+    from control_amd.fem import rectangle_p1
+    disc = rectangle_p1(N, N, 2.0, 2.0)
+    beta, t_f = 1.0, 2.0
+    pi2 = np.pi * np.pi
+
+    def c(X):
+        return np.cos(0.5 * np.pi * (X[:, 0] - 1.0)) * np.cos(0.5 * np.pi * (X[:, 1] - 1.0))
+
+    def ref_v(X, t):
+        return 1.0 + ((2.0 / (pi2 * beta)) * np.exp(t_f)
+                      - (2.0 / ((2.0 + pi2) * beta)) * np.exp(t)) * c(X)
+
+    def ref_zeta(X, t):
+        return (np.exp(t_f) - np.exp(t)) * c(X)
+
+    def desired_state(X, t):
+        return 1.0 + ((2.0 / (pi2 * beta) + 0.5 * pi2) * np.exp(t_f)
+                      + (1.0 - 2.0 / ((2.0 + pi2) * beta) - 0.5 * pi2) * np.exp(t)) * c(X)
+
+    ctl = Instationary(disc, desired_state=desired_state, force_f=None, beta=beta, CN=CN,
+                       n_t=n_t, initial_condition=lambda X: ref_v(X, 0.0),
+                       time_interval=(0.0, t_f), bcs_v=lambda Xb, t: np.ones(len(Xb)))
+    return ctl, disc, ref_v, ref_zeta
+
+
 def mms_convection_diffusion_control(N, CN, n_t=10):
     """``test/test_control.py:2297-2440``: the heat problem above with the time-dependent,
     divergence-free wind ``cos(pi t / 2) (2 y (1 - x^2), -2 x (1 - y^2))`` (coordinates shifted

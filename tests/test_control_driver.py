@@ -49,6 +49,55 @@ def test_mms_heat_control_on_the_gpu(CN):
 
 
 @pytest.mark.parametrize("CN", [False, True])
+def test_time_discretisation_orders_with_the_oracle(CN):
+    """``test/test_control.py:1829-1980`` (BE) / ``2140-2294`` (CN): exact solution exponential in
+    time.  The reference compares with the exact solution on ``N = 250`` for ``n_t = 4 .. 32``;
+    here the time grids are nested (``n_t = 5, 9, 17, 33``: the step halves and the coarse levels
+    are levels of the fine grid) on ``N = 24`` and the order is read off the differences of
+    successive solutions at the common levels, in which the spatial error cancels: first order
+    for BE (0.84 / 0.92 then 0.92 / 0.95 measured for state / adjoint), second for CN (2.21 /
+    2.19 then 2.04 / 2.06).  This is the check that sees a wrong factor of tau or a wrong
+    ``T_1`` / ``T_2`` in the rows: the linear-in-time problems above are exact in time for
+    both schemes."""
+    sols = {}
+    for n_t in (5, 9, 17, 33):
+        ctl, disc, _, _ = common.mms_heat_control_in_time(24, CN, n_t)
+        ksp = ctl.linear_solve(solver_parameters=common.MMS_SOLVER_PARAMETERS,
+                               lambda_v_bounds=(0.5, 2.0),
+                               backend=common.OracleBackend(schur=(40, 0.01, 2.2)))
+        assert ksp.reason > 0
+        sols[n_t] = (ctl._v.copy(), ctl._zeta.copy())
+    diffs = []
+    for a, b in ((5, 9), (9, 17), (17, 33)):
+        tau = 2.0 / (a - 1)
+        diffs.append([np.sqrt(tau * sum(x @ (disc.M @ x) for x in sols[a][k] - sols[b][k][::2]))
+                      for k in (0, 1)])
+    diffs = np.array(diffs)
+    orders = np.log(diffs[:-1] / diffs[1:]) / np.log(2.0)
+    if CN:
+        assert orders.min() > 1.9 and orders.max() < 2.4, orders
+    else:
+        assert orders.min() > 0.8 and orders.max() < 1.1, orders
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("CN", [False, True])
+def test_time_dependent_mms_on_the_gpu(CN):
+    from control_amd.control import GpuBackend
+    out = []
+    for be in (GpuBackend(schur=(40, 0.01, 2.2)), common.OracleBackend(schur=(40, 0.01, 2.2))):
+        ctl, disc, ref_v, ref_zeta = common.mms_heat_control_in_time(24, CN, 9)
+        ksp = ctl.linear_solve(solver_parameters=common.MMS_SOLVER_PARAMETERS,
+                               lambda_v_bounds=(0.5, 2.0), backend=be)
+        assert ksp.reason > 0
+        out.append((ctl._v.copy(), ctl._zeta.copy()))
+    assert np.abs(out[0][0] - out[1][0]).max() < 1e-7
+    assert np.abs(out[0][1] - out[1][1]).max() < 1e-7
+    ev, ez = common.mms_errors(ctl, disc, ref_v, ref_zeta, n_t=9)
+    assert ev < (0.01 if CN else 0.1) and ez < (0.02 if CN else 0.3)
+
+
+@pytest.mark.parametrize("CN", [False, True])
 def test_mms_convection_diffusion_control_orders_with_the_oracle(CN):
     """``test/test_control.py:2297-2493`` (BE; the CN run keeps the BE data, see the helper):
     a non-symmetric forward operator that changes with the time level.  P1 orders asserted
