@@ -381,6 +381,53 @@ def stokes_exact_sol_control(CN, n=8, n_t=20):
     return ctl, th, true_v
 
 
+def mms_stokes_control_instationary(N, CN, n_t=10):
+    """``test/test_control.py:3305-3460`` (BE) / ``3754-3905`` (CN): instationary Stokes control,
+    Taylor-Hood P2-P1 on ``RectangleMesh(N, N, 2, 2)``, beta = 1e-3, polynomial exact solution
+    linear in time, time-dependent inhomogeneous Dirichlet data."""
+    from control_amd.control import Instationary
+    from control_amd.fem import rectangle_p2p1
+    th = rectangle_p2p1(N, N, 2.0, 2.0)
+    t_f, beta = 2.0, 1.0e-3
+
+    def xy(X):
+        return X[:, 0] - 1.0, X[:, 1] - 1.0
+
+    def v_space(X):
+        x, y = xy(X)
+        return np.concatenate([x * y**3, 0.25 * (x**4 - y**4)])
+
+    def g(X):                      # zeta = beta (t_f - t) g
+        x, y = xy(X)
+        return np.concatenate([2.0 * y * (x**2 - 1.0)**2 * (y**2 - 1.0),
+                               -2.0 * x * (x**2 - 1.0) * (y**2 - 1.0)**2])
+
+    def lapl_g(X):
+        x, y = xy(X)
+        return np.concatenate([
+            2.0 * y * (y**2 - 1.0) * (12.0 * x**2 - 4.0) + 12.0 * y * (x**2 - 1.0)**2,
+            -12.0 * x * (y**2 - 1.0)**2 - 2.0 * x * (x**2 - 1.0) * (12.0 * y**2 - 4.0)])
+
+    def true_v(X, t):
+        return (t_f - t) * v_space(X)
+
+    def true_zeta(X, t):
+        return beta * (t_f - t) * g(X)
+
+    def desired_state(X, t):       # v + zeta_space - lapl(zeta) + grad(mu), mu = beta (t_f - t) 4 x y
+        x, y = xy(X)
+        return (true_v(X, t) + beta * g(X) - beta * (t_f - t) * lapl_g(X)
+                + beta * (t_f - t) * np.concatenate([4.0 * y, 4.0 * x]))
+
+    def force_f(X, t):             # - v_space - lapl(v) + grad(p) - zeta / beta, -lapl(v) + grad(p) = 0
+        return -v_space(X) - (t_f - t) * g(X)
+
+    ctl = Instationary(th, desired_state=desired_state, force_f=force_f, beta=beta,
+                       initial_condition=lambda X: true_v(X, 0.0), time_interval=(0.0, t_f),
+                       CN=CN, n_t=n_t, bcs_v=lambda Xb, t: true_v(Xb, t))
+    return ctl, th, true_v, true_zeta
+
+
 def _oracle_backend_stokes_pc_stationary(self, th, D_v, D_p, beta, lambda_v_bounds,
                                          lambda_p_bounds):
     ko = self._ko

@@ -161,6 +161,58 @@ def test_instationary_stokes_control_with_exact_sol_oracle(CN):
     assert np.all(ctl._zeta[:, th.boundary_v] == 0.0)
 
 
+def _stokes_mms_errors(ctl, th, true_v, true_zeta, n_t=10, t_f=2.0):
+    tau = t_f / (n_t - 1.0)
+    ev = ez = 0.0
+    for i in range(n_t):
+        d = ctl._v[i] - true_v(th.coords_v, i * tau)
+        ev += tau * (d @ (th.M_v @ d))
+        d = ctl._zeta[i] - true_zeta(th.coords_v, i * tau)
+        ez += tau * (d @ (th.M_v @ d))
+    return np.sqrt(ev), np.sqrt(ez)
+
+
+STOKES_MMS_BOUNDS = dict(lambda_v_bounds=(0.3924, 2.0598), lambda_p_bounds=(0.5, 2.0))   # :3476
+
+
+@pytest.mark.parametrize("CN", [False, True])
+def test_mms_instationary_stokes_control_orders_with_the_oracle(CN):
+    """``test/test_control.py:3305-3543`` (BE) / ``3754-3962`` (CN), Taylor-Hood P2-P1 (degree 2
+    of the reference's 2 and 3), beta = 1e-3, time-dependent inhomogeneous Dirichlet data.
+    The reference prints the orders; here: at least third order for velocity and adjoint
+    between N = 4 and N = 8 (measured against the nodal interpolant of the exact solution:
+    3.84 / 3.91 BE, 3.72 / 3.97 CN)."""
+    errs = []
+    for N in ((2, 4, 8) if not CN else (4, 8)):
+        ctl, th, true_v, true_zeta = common.mms_stokes_control_instationary(N, CN)
+        ksp = ctl.incompressible_linear_solve(solver_parameters=common.MMS_SOLVER_PARAMETERS,
+                                              backend=common.OracleBackend(schur=(40, 0.01, 2.3)),
+                                              **STOKES_MMS_BOUNDS)
+        assert ksp.reason > 0
+        errs.append(_stokes_mms_errors(ctl, th, true_v, true_zeta))
+    errs = np.array(errs)
+    orders = np.log(errs[:-1] / errs[1:]) / np.log(2.0)
+    assert orders.min() > 3.0, (errs, orders)
+    assert errs[-1][0] < 1e-3 and errs[-1][1] < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("CN", [False, True])
+def test_mms_instationary_stokes_control_on_the_gpu(CN):
+    from control_amd.control import GpuBackend
+    out = []
+    for be in (GpuBackend(schur=(40, 0.01, 2.3)), common.OracleBackend(schur=(40, 0.01, 2.3))):
+        ctl, th, true_v, true_zeta = common.mms_stokes_control_instationary(8, CN)
+        ksp = ctl.incompressible_linear_solve(solver_parameters=common.MMS_SOLVER_PARAMETERS,
+                                              backend=be, **STOKES_MMS_BOUNDS)
+        assert ksp.reason > 0
+        out.append((ctl._v.copy(), ctl._zeta.copy(), ctl._p.copy()))
+    assert np.abs(out[0][0] - out[1][0]).max() < 1e-7
+    assert np.abs(out[0][1] - out[1][1]).max() < 1e-8
+    ev, ez = _stokes_mms_errors(ctl, th, true_v, true_zeta)
+    assert ev < 1e-3 and ez < 1e-5
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("CN", [False, True])
 def test_instationary_stokes_control_with_exact_sol_gpu(CN):
