@@ -142,6 +142,39 @@ def navier_stokes_problem(n=4, n_t=4, nu=0.1, beta=1.0e-2, T=2.0, CN=False):
                                f=np.zeros((n_t, th.n_v)), CN=CN)
 
 
+def navier_stokes_cavity_problem(n=8, n_t=10, CN=False):
+    """``test/test_control.py:4171-4268`` (BE) / ``4271-4368`` (CN): Navier-Stokes control in the
+    lid-driven cavity.  P2-P1 on ``RectangleMesh(n, n, 2, 2)``, nu = 1/100, beta = 1e-3,
+    T = 2; the lid (boundary 4, ``y = 2``; its corners belong to the no-slip walls because the
+    wall condition is applied last) moves with ``(min(t, 1), 0)``; the desired state is a pair
+    of counter-rotating vortices modulated by ``cos(pi t / 2)``; zero force and initial state.
+    Returns the problem and the initial iterate that carries the Dirichlet values of every
+    time level (``control.py:4925-4959``: the loop starts from ``v`` with the conditions
+    applied and solves for updates that vanish on the boundary)."""
+    from control_amd.fem import rectangle_p2p1
+    from control_amd.picard import NavierStokesControl
+    th = rectangle_p2p1(n, n, 2.0, 2.0)
+    T = 2.0
+    tau = T / (n_t - 1.0)
+    nn = th.n_v // 2
+    X, Y = th.coords_v[:nn, 0], th.coords_v[:nn, 1]
+    x, y = X - 1.0, Y - 1.0
+    a, b = (100.0 / 49.0) ** 2, (100.0 / 99.0) ** 2
+    c_1 = 1.0 - np.sqrt(a * (x - 0.5) ** 2 + b * y ** 2)
+    c_2 = 1.0 - np.sqrt(a * (x + 0.5) ** 2 + b * y ** 2)
+    vx = np.where(c_1 >= 0.0, c_1 * b * y, np.where(c_2 >= 0.0, -c_2 * b * y, 0.0))
+    vy = np.where(c_1 >= 0.0, -c_1 * a * (x - 0.5), np.where(c_2 >= 0.0, c_2 * a * (x + 0.5), 0.0))
+    shape = np.concatenate([vx, vy])
+    v_d = np.stack([np.cos(0.5 * np.pi * i * tau) * shape for i in range(n_t)])
+    pb = NavierStokesControl(disc=th, nu=1.0 / 100.0, beta=1.0e-3, n_t=n_t, T=T, v_d=v_d,
+                             f=np.zeros((n_t, th.n_v)), CN=CN)
+    lid = np.flatnonzero((np.abs(Y - 2.0) < 1e-12) & (X > 1e-12) & (X < 2.0 - 1e-12))
+    v_init = np.zeros((n_t, th.n_v))
+    for i in range(n_t):
+        v_init[i, lid] = min(i * tau, 1.0)           # first component on the lid nodes
+    return pb, v_init, lid
+
+
 class OracleLinearSolver:
     """The linearised solve of one Picard iteration in the CPU oracle (rebuilt every time)."""
 
