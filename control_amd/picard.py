@@ -13,8 +13,10 @@ the reference; each outer iteration re-uploads only the values of the blocks tha
 matrices refreshed on the device) and runs the linear solve on the GPU through
 ``MultiBlockSystem.solve`` with a ``StokesPC``.
 
-Homogeneous Dirichlet velocity conditions (``bcs_v``, ``bcs_zeta``); the lifting of
-inhomogeneous ones belongs to the right-hand-side construction.
+Dirichlet velocity conditions: the updates vanish on the boundary (``bcs_v`` homogenised,
+``bcs_zeta``); inhomogeneous, time-dependent values ride on the initial iterate ``v`` the
+caller passes (``control.py:4925-4959`` applies the conditions to ``v_old`` before the loop),
+as in the lid-driven cavity of ``test/test_control.py:4171-4268``.
 """
 from __future__ import annotations
 
