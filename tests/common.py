@@ -175,6 +175,40 @@ def navier_stokes_cavity_problem(n=8, n_t=10, CN=False):
     return pb, v_init, lid
 
 
+def mms_navier_stokes_control(N, CN=False, n_t=10, nu=1.0 / 50.0):
+    """``test/test_control.py:4371-4470`` (BE) / ``4740-4840`` (CN): Navier-Stokes control with
+    the manufactured solution ``v = (T - t) (x y^3, (x^4 - y^4) / 4)`` (divergence free),
+    ``zeta = 0``, ``v_d = v``; nu = 1/50, beta = 1e-3, T = 2, P2-P1 on
+    ``RectangleMesh(N, N, 2, 2)``; the force is ``-nu/2 lapl(v) + (v . grad) v - v_xy`` (the
+    other half of the viscous term is a gradient and lands in the pressure).  Returns the
+    problem, the initial iterate (exact boundary values on every level, zero inside) and the
+    exact velocity."""
+    from control_amd.fem import rectangle_p2p1
+    from control_amd.picard import NavierStokesControl
+    th = rectangle_p2p1(N, N, 2.0, 2.0)
+    T, beta = 2.0, 1.0e-3
+    tau = T / (n_t - 1.0)
+    nn = th.n_v // 2
+    x, y = th.coords_v[:nn, 0] - 1.0, th.coords_v[:nn, 1] - 1.0
+    u1, u2 = x * y**3, 0.25 * (x**4 - y**4)
+    v_xy = np.concatenate([u1, u2])
+    lapl = np.concatenate([6.0 * x * y, 3.0 * x**2 - 3.0 * y**2])
+    conv = np.concatenate([u1 * y**3 + u2 * 3.0 * x * y**2,        # (v_xy . grad) v_xy
+                           u1 * x**3 - u2 * y**3])
+
+    def true_v(t):
+        return (T - t) * v_xy
+
+    f = np.stack([-0.5 * nu * (T - i * tau) * lapl + (T - i * tau) ** 2 * conv - v_xy
+                  for i in range(n_t)])
+    v_d = np.stack([true_v(i * tau) for i in range(n_t)])
+    pb = NavierStokesControl(disc=th, nu=nu, beta=beta, n_t=n_t, T=T, v_d=v_d, f=f,
+                             v_0=true_v(0.0), CN=CN)
+    v_init = np.zeros((n_t, th.n_v))
+    v_init[:, th.boundary_v] = v_d[:, th.boundary_v]
+    return pb, v_init, true_v
+
+
 class OracleLinearSolver:
     """The linearised solve of one Picard iteration in the CPU oracle (rebuilt every time)."""
 
