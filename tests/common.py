@@ -407,14 +407,15 @@ OracleBackend.construct_stokes_pc = _oracle_backend_stokes_pc
 OracleBackend.ConstantNullspace = property(lambda self: self._ko.ConstantNullspace)
 
 
-def stokes_exact_sol_control(CN, n=8, n_t=20):
+def stokes_exact_sol_control(CN, n=8, n_t=20, T_f=1.0, beta=1.0, taylor_hood=False):
     """``test/test_control.py:3045-3172`` (BE) / ``3175-3302`` (CN): instationary Stokes
     control with an exact solution, Q2-Q1 on ``RectangleMesh(8, 8, 2, 2, quadrilateral=True)``,
-    beta = 1, time-dependent inhomogeneous Dirichlet data."""
+    beta = 1, time-dependent inhomogeneous Dirichlet data.  The time-convergence tests
+    ``3546-3751`` (BE) / ``3965-4168`` (CN) use the same solution with ``T_f = 2``,
+    ``beta = 1e-3`` on Taylor-Hood P2-P1 triangles (``taylor_hood=True``)."""
     from control_amd.control import Instationary
-    from control_amd.fem import unit_square_q2q1
-    th = unit_square_q2q1(n, 2.0)
-    T_f, beta = 1.0, 1.0
+    from control_amd.fem import rectangle_p2p1, unit_square_q2q1
+    th = rectangle_p2p1(n, n, 2.0, 2.0) if taylor_hood else unit_square_q2q1(n, 2.0)
 
     def true_v(X, t):
         x, y = X[:, 0] - 1.0, X[:, 1] - 1.0

@@ -215,6 +215,39 @@ def test_mms_instationary_stokes_control_on_the_gpu(CN):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("CN", [False, True])
+def test_stokes_control_time_discretisation_orders_on_the_gpu(CN):
+    """``test/test_control.py:3546-3751`` (BE) / ``3965-4168`` (CN): Stokes control with the
+    exact solution ``exp(T - t) (x y^3, (x^4 - y^4) / 4)``, Taylor-Hood P2-P1, beta = 1e-3,
+    T = 2, time-dependent Dirichlet data.  The reference runs N = 100 and prints the orders;
+    here N = 32 (spatial error 1e-5, below the time errors compared) with n_t = 5, 9, 17 and the
+    error against the exact velocity: first order for BE (0.89, 0.94 measured), second for
+    CN (2.41, 1.91) -- the check of the incompressible driver's CN rows (``T_1`` / ``T_2`` on
+    velocity and pressure blocks, ``sub_n_blocks``) with a real time-discretisation error.
+    GPU only: the oracle's nested preconditioner needs minutes at this size."""
+    from control_amd.control import GpuBackend
+    errs = []
+    for n_t in (5, 9, 17):
+        ctl, th, true_v = common.stokes_exact_sol_control(CN, n=32, n_t=n_t, T_f=2.0, beta=1e-3,
+                                                          taylor_hood=True)
+        ksp = ctl.incompressible_linear_solve(solver_parameters=common.MMS_SOLVER_PARAMETERS,
+                                              backend=GpuBackend(schur=(60, 0.002, 2.3)),
+                                              **STOKES_MMS_BOUNDS)
+        assert ksp.reason > 0
+        tau = 2.0 / (n_t - 1.0)
+        e2 = 0.0
+        for i in range(n_t):
+            d = ctl._v[i] - true_v(th.coords_v, i * tau)
+            e2 += tau * (d @ (th.M_v @ d))
+        errs.append(np.sqrt(e2))
+    orders = np.log(np.array(errs[:-1]) / np.array(errs[1:])) / np.log(2.0)
+    if CN:
+        assert orders.min() > 1.7, (errs, orders)
+    else:
+        assert 0.8 < orders.min() and orders.max() < 1.2, (errs, orders)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("CN", [False, True])
 def test_instationary_stokes_control_with_exact_sol_gpu(CN):
     from control_amd.control import GpuBackend
     sp_ = {"linear_solver": "fgmres", "fgmres_restart": 10, "maximum_iterations": 200,
