@@ -751,6 +751,31 @@ def test_suggested_chebyshev_parameters_make_the_solve_converge():
                    pc_fn=common.oracle_pc(p, (20, 0.5, 2.0), (8, 0.07, 2.1)))
 
 
+def test_suggested_chebyshev_parameters_on_a_3d_block_need_no_factorisation():
+    """Both ends of the spectrum come from plain Lanczos: a 3-D block (here 24^3; 64^3 takes
+    2.7 s) costs seconds, where a shift-invert estimate -- a sparse LU with 3-D fill-in -- did
+    not finish in minutes.  The interval must contain the dense spectrum of a small block."""
+    import time
+    from control_amd.blocks import instationary_blocks
+    from control_amd.control import suggest_chebyshev
+    from control_amd.fem import unit_cube_p1
+    sd = unit_cube_p1(24)
+    tau, beta = 2.0 / 31.0, 1.0e-4
+    t0 = time.perf_counter()
+    its, emin, emax = suggest_chebyshev(tau * sd.K + sd.M, sd.M, tau / np.sqrt(beta), sd.boundary)
+    assert time.perf_counter() - t0 < 30.0
+    assert 4 <= its <= 40 and 0.0 < emin < 0.2 and 1.5 < emax < 2.6
+    small = unit_cube_p1(6)
+    L = (tau * small.K + small.M + (tau / np.sqrt(beta)) * small.M).toarray()
+    keep = np.setdiff1d(np.arange(small.n_dofs), small.boundary)
+    L = L[np.ix_(keep, keep)]
+    d = 1.0 / np.sqrt(np.diag(L))
+    ev = np.linalg.eigvalsh(d[:, None] * L * d[None, :])
+    _, lo, hi = suggest_chebyshev(tau * small.K + small.M, small.M, tau / np.sqrt(beta),
+                                  small.boundary)
+    assert lo <= ev[0] and ev[-1] <= hi and lo > 0.9 * ev[0] and hi < 1.1 * ev[-1]
+
+
 @pytest.mark.gpu
 def test_gpu_backend_default_parameters_converge():
     """``GpuBackend()`` without arguments picks the sweeps itself."""
