@@ -242,3 +242,24 @@ def test_row_sorted_storage_is_bit_identical(monkeypatch):
     assert np.array_equal(outs[0][0], outs[1][0])
     assert np.array_equal(outs[0][1], outs[1][1])
     assert infos[1]["bytes_device_values"] < 0.85 * infos[0]["bytes_device_values"]
+
+
+def test_mid_size_mesh_long_sweep_program_matches_plain_launches(monkeypatch):
+    """A mesh with more than 1 024 slices (401^2 nodes: 1 257) runs the data-flow sweep program
+    with multi-wave workgroups; with 4-wave workgroups, two to a CU, programs of about 1 000
+    phases timed out waiting for a neighbour (error -2).  The shapes in use -- one-wave
+    workgroups, or one 8-wave workgroup per CU -- must reproduce the plain launches bit for
+    bit on a program of 972 phases."""
+    import bench
+
+    class A:
+        workload, n, n_t, beta, T, scheme, mode = "heat2d", 400, 12, 1e-4, 2.0, "BE", "G"
+        schur_its, schur_emin, schur_emax = 80, 7e-4, 2.1
+    p = bench.build_problem(A())
+    x = common.rng_vector(2 * p["m"] * p["sd"].n_dofs)
+    g = common.gpu_system(p)
+    y = g.pc_apply(x, common.gpu_pc(p, p["mass"], p["schur"]))
+    monkeypatch.setenv("KKT_PERSISTENT", "0")
+    g2 = common.gpu_system(p)
+    y2 = g2.pc_apply(x, common.gpu_pc(p, p["mass"], p["schur"]))
+    assert np.array_equal(y, y2)
