@@ -129,8 +129,20 @@ void SchurPC::fuse_programs() {
         // while all of them are co-resident; else 4 / 8 waves per workgroup
         const char *pw = std::getenv("KKT_PROG_WAVES");
         const int first = pw ? std::atoi(pw) : (try_g ? 1 : 4);
+        int n_cus = 0, dev_id = 0;
+        if (hipGetDevice(&dev_id) != hipSuccess ||
+            hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess)
+            n_cus = 0;
+        // Multi-wave workgroups: one per CU is the shape preferred (pass 0).  Two 4-wave
+        // workgroups of the data-flow form on a CU did not stay co-resident reliably (below);
+        // the counter form has run that way (P2 Stokes: 259 workgroups) without a failure, so it
+        // remains the fallback (pass 1) when no one-per-CU shape fits.
+        for (int pass = 0; pass < 2 && !wpw; ++pass)
         for (int cand : {first, 4, 8}) {
             if (cand < 1 || cand > 8) continue;
+            if (pass == 0 && cand > 1 && !(pw && cand == first) &&
+                (P.nslices + cand - 1) / cand > n_cus)
+                continue;
             // data-flow form with two 4-wave workgroups on a CU: long programs (about 1 000
             // phases and more; 401^2 mesh, 315 workgroups) ran into the bounded spin of a wave
             // waiting for a neighbour (reported, results discarded).  One-wave workgroups and
