@@ -48,7 +48,7 @@ class Info(C.Structure):
     _fields_ = [(n, C.c_int64) for n in
                 ("n_local", "n_blocks_stored", "n_value_arrays", "n_patterns",
                  "nnz_blocks", "rows_blocks", "bytes_algorithmic",
-                 "bytes_device_values", "bytes_device_index")] + \
+                 "bytes_device_values", "bytes_device_index", "bytes_streamed")] + \
                [("last_solve_ms", C.c_double), ("last_pc_applies", C.c_int64),
                 ("last_op_applies", C.c_int64)]
 
@@ -66,6 +66,7 @@ SIGNATURES = {
     "kkt_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "kkt_destroy": (C.c_int, [C.c_void_p]),
     "kkt_last_error": (C.c_char_p, [C.c_void_p]),
+    "kkt_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "kkt_set_layout": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                  C.c_int, C.c_int, C.c_int]),
     "kkt_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

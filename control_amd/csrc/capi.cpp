@@ -63,6 +63,20 @@ int kkt_destroy(kkt_handle h) {
 
 const char *kkt_last_error(kkt_handle h) { return h ? h->S.err.c_str() : g_create_error.c_str(); }
 
+int kkt_set_option(kkt_handle h, const char *key, const char *value) {
+    KKT_TRY(h, {
+        static const char *known[] = {"sell_r", "sell_sort", "no_graph", "persistent", "prog_mode",
+                                      "prog_waves", "prog_steps", "tile_depth", "tile_waves",
+                                      "lanes", "lane_chunks", "kernarg_ops", "shared_rows",
+                                      "verbose"};
+        if (!key || !value) fail(KKT_ERR_ARG, "null option");
+        bool ok = false;
+        for (const char *k : known) ok = ok || std::strcmp(k, key) == 0;
+        if (!ok) fail(KKT_ERR_ARG, std::string("unknown option: ") + key);
+        S.options[key] = value;
+    });
+}
+
 int kkt_set_layout(kkt_handle h, int n00, int n11, int64_t nx0, int64_t nx1, int CN, int s00,
                    int s11) {
     KKT_TRY(h, S.set_layout(n00, n11, nx0, nx1, CN, s00, s11));

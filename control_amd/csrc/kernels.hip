@@ -1581,6 +1581,18 @@ void launch_vals_axpy(hipStream_t s, double *out, const double *a, double c,
                        c, b, n_padded);
 }
 
+__global__ void vals_differ_kernel(const double *__restrict__ a, const double *__restrict__ b,
+                                   int64_t n, unsigned *flag) {
+    bool d = false;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n;
+         p += (int64_t)gridDim.x * blockDim.x)
+        d |= __double_as_longlong(a[p]) != __double_as_longlong(b[p]);
+    if (d) atomicOr(flag, 1u);
+}
+void launch_vals_differ(hipStream_t s, const double *a, const double *b, int64_t n, unsigned *flag) {
+    hipLaunchKernelGGL(vals_differ_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, b, n, flag);
+}
+
 template <int R>
 __global__ void extract_dinv_kernel(const int32_t *__restrict__ col,
                                     const int32_t *__restrict__ slice_off,
@@ -1934,6 +1946,67 @@ void launch_maxpy(hipStream_t s, double *w, VecList V, const double *coef, doubl
         case 7: hipLaunchKernelGGL(maxpy_kernel<7>, g, b, 0, s, w, V, coef, sign, n); break;
         default: hipLaunchKernelGGL(maxpy_kernel<8>, g, b, 0, s, w, V, coef, sign, n); break;
     }
+}
+
+// maxpy with the partial sums of the squared norm of the result, in the chunks and the
+// summation order of mdot_stage1 (so the norm equals a separate mdot(w, w) bit for bit);
+// followed by mdot_stage2 on one column.
+template <int NV>
+__global__ __launch_bounds__(256) void maxpy_norm_kernel(double *__restrict__ w, VecList V,
+                                                         const double *__restrict__ coef,
+                                                         double sign, int64_t n,
+                                                         double *__restrict__ part) {
+    __shared__ double sh[4];
+    double c[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) c[i] = coef[i];
+    const int64_t chunk = ((n + REDUCE_BLOCKS - 1) / REDUCE_BLOCKS + 1) & ~(int64_t)1;
+    const int64_t lo = (int64_t)blockIdx.x * chunk;
+    int64_t hi = lo + chunk;
+    if (hi > n) hi = n;
+    double acc = 0.0;
+    int64_t p = lo + 2 * (int64_t)threadIdx.x;
+    for (; p + 1 < hi; p += 512) {
+        double ax = 0.0, ay = 0.0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const d2 vv = *reinterpret_cast<const d2 *>(V.v[i] + p);
+            ax = __builtin_fma(c[i], vv.x, ax);
+            ay = __builtin_fma(c[i], vv.y, ay);
+        }
+        d2 wv = *reinterpret_cast<const d2 *>(w + p);
+        wv.x = __builtin_fma(sign, ax, wv.x);
+        wv.y = __builtin_fma(sign, ay, wv.y);
+        *reinterpret_cast<d2 *>(w + p) = wv;
+        acc = __builtin_fma(wv.x, wv.x, acc);
+        acc = __builtin_fma(wv.y, wv.y, acc);
+    }
+    if (p < hi) {
+        double a = 0.0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) a = __builtin_fma(c[i], V.v[i][p], a);
+        const double wv = __builtin_fma(sign, a, w[p]);
+        w[p] = wv;
+        acc = __builtin_fma(wv, wv, acc);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const double t = wave_sum(acc);
+    if (lane == 0) sh[wave] = t;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        part[(int64_t)blockIdx.x * MDOT_MAX] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+void launch_maxpy_norm(hipStream_t s, double *w, VecList V, const double *coef, double sign,
+                       int nv, int64_t n, double *scratch, double *out_sq) {
+    if (nv <= 0 || n <= 0) return;
+    dim3 g(REDUCE_BLOCKS), b(256);
+    switch (nv) {
+#define KKT_N(k) case k: hipLaunchKernelGGL(maxpy_norm_kernel<k>, g, b, 0, s, w, V, coef, sign, n, scratch); break;
+        KKT_N(1) KKT_N(2) KKT_N(3) KKT_N(4) KKT_N(5) KKT_N(6) KKT_N(7)
+        default: hipLaunchKernelGGL(maxpy_norm_kernel<8>, g, b, 0, s, w, V, coef, sign, n, scratch); break;
+#undef KKT_N
+    }
+    hipLaunchKernelGGL(mdot_stage2, dim3(1), b, 0, s, scratch, out_sq);
 }
 
 __global__ void scale_inv_kernel(double *__restrict__ y, const double *__restrict__ x,

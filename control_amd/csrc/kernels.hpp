@@ -99,6 +99,8 @@ void launch_mask_columns(hipStream_t s, double *sell_vals, const int32_t *col,
 // out = a + c * b (no fma contraction: matches "assemble(block + c * M)")
 void launch_vals_axpy(hipStream_t s, double *out, const double *a, double c,
                       const double *b, int64_t n_padded);
+// *flag |= 1 when a and b differ in any bit
+void launch_vals_differ(hipStream_t s, const double *a, const double *b, int64_t n, unsigned *flag);
 // dinv[r] = rowmask[r] ? 1 : 1 / diag(A)[r]
 void launch_extract_dinv(hipStream_t s, const int32_t *col, const int32_t *slice_off,
                          const double *vals, const uint8_t *rowmask, double *dinv,
@@ -140,6 +142,9 @@ void launch_norm2_finish(hipStream_t s, const double *dot, double *out);
 // w += sign * sum_i coef[i] * V_i   (coef in device memory)
 void launch_maxpy(hipStream_t s, double *w, VecList V, const double *coef, double sign,
                   int nv, int64_t n);
+// the same update, and out_sq[0] = <w, w> of the updated w (summation order of launch_mdot)
+void launch_maxpy_norm(hipStream_t s, double *w, VecList V, const double *coef, double sign,
+                       int nv, int64_t n, double *scratch, double *out_sq);
 // y = x * (1 / *norm)
 void launch_scale_inv(hipStream_t s, double *y, const double *x, const double *norm,
                       int64_t n);

@@ -141,10 +141,17 @@ void System::pc_apply_timed(const double *d_x, double *d_y, float *ms, int *laun
 namespace {
 
 struct Conv {   // KSPConvergedDefault
-    double atol, divtol, rnorm0, ttol;
-    Conv(double rtol, double atol_, double divtol_, double rnorm0_)
-        : atol(atol_), divtol(divtol_), rnorm0(rnorm0_), ttol(std::max(rtol * rnorm0_, atol_)) {}
-    int operator()(double rn) const {
+    double rtol, atol, divtol, rnorm0, ttol;
+    Conv(double rtol_, double atol_, double divtol_, double rnorm0_)
+        : rtol(rtol_), atol(atol_), divtol(divtol_), rnorm0(rnorm0_),
+          ttol(std::max(rtol_ * rnorm0_, atol_)) {}
+    int operator()(double rn) {
+        // "handle special case of zero RHS and nonzero guess": the first residual norm takes
+        // the place of the (zero) right-hand-side norm
+        if (rnorm0 == 0.0 && std::isfinite(rn)) {
+            rnorm0 = rn;
+            ttol = std::max(rtol * rn, atol);
+        }
         if (!std::isfinite(rn)) return KKT_DIVERGED_NANORINF;
         if (rn <= ttol) return rn < atol ? KKT_CONVERGED_ATOL : KKT_CONVERGED_RTOL;
         if (rn >= divtol * rnorm0) return KKT_DIVERGED_DTOL;
@@ -192,7 +199,7 @@ void System::solve_minres(const double *d_b, double *d_u, int *its_out, int *rea
     const double haptol = 1.0e-50;
 
     pc_apply(b, Z);
-    const Conv conv(ksp.rtol, ksp.atol, ksp.divtol, std::sqrt(dot(Z, Z)));
+    Conv conv(ksp.rtol, ksp.atol, ksp.divtol, std::sqrt(dot(Z, Z)));
     for (double *p : {UOLD, VOLD, W, WOLD, WOOLD}) launch_fill(stream, p, 0.0, n_local);
     apply(d_u, R);
     launch_axpby(stream, R, 1.0, b, -1.0, n_local);   // r = b - A x
@@ -269,6 +276,7 @@ void System::solve_minres(const double *d_b, double *d_u, int *its_out, int *rea
     }
     ns_project(d_u, d_u);
     sync();
+    if (pc) pc->check();
     info.last_solve_ms =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     if (its_out) *its_out = its;
@@ -323,7 +331,7 @@ void System::solve(const double *d_b, double *d_u, int *its_out, int *reason_out
     }
     read_scalars(d_hcol, 1);
     rnorm0 = h_pinned[0];
-    const Conv conv(ksp.rtol, ksp.atol, ksp.divtol, rnorm0);
+    Conv conv(ksp.rtol, ksp.atol, ksp.divtol, rnorm0);
     const double haptol = 1.0e-30;
 
     std::vector<double> H((size_t)(m + 1) * m, 0.0), cc(m, 0.0), ss(m, 0.0), grs(m + 1, 0.0);
@@ -370,14 +378,22 @@ void System::solve(const double *d_b, double *d_u, int *its_out, int *reason_out
             std::vector<const double *> Vl(it + 1);
             for (int k = 0; k <= it; ++k) Vl[k] = Vp(k);
             mdot(w, Vl.data(), it + 1, d_hcol);
+            // the last update pass also leaves the partial sums of ||w||^2 (one pass over w
+            // less; same chunks and summation order as mdot_stage1, so tt is bitwise the norm a
+            // separate pass would give)
+            double *d_tt = d_hcol + (it + 1);   // [tt, scratch]
             for (int g = 0; g <= it; g += MDOT_MAX) {
                 const int mm = std::min(MDOT_MAX, it + 1 - g);
                 VecList L{};
                 for (int i = 0; i < mm; ++i) L.v[i] = Vl[g + i];
-                launch_maxpy(stream, w, L, d_hcol + g, -1.0, mm, n_local);
+                if (g + MDOT_MAX > it)
+                    launch_maxpy_norm(stream, w, L, d_hcol + g, -1.0, mm, n_local, d_red_scratch,
+                                      d_tt + 1);
+                else
+                    launch_maxpy(stream, w, L, d_hcol + g, -1.0, mm, n_local);
             }
-            double *d_tt = d_hcol + (it + 1);   // [tt, scratch]
-            norm2(w, d_tt);
+            if (sharded) comm->allreduce_sum(d_tt + 1, 1, stream);
+            launch_norm2_finish(stream, d_tt + 1, d_tt);
             read_scalars(d_hcol, it + 2);
             for (int k = 0; k <= it; ++k) Hm(k, it) = h_pinned[k];
             const double tt = h_pinned[it + 1];

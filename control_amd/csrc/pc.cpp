@@ -41,13 +41,13 @@ SchurPC::SchurPC(System &S, const kkt_pc_desc &d) : S_(S), d_(d) {
     d_.m_indptr = d_.m_indices = nullptr;
     d_.m_values = nullptr;
     d_.bc_idx = nullptr;
-    const char *e = std::getenv("KKT_NO_GRAPH");
+    const char *e = S_.opt("no_graph");
     use_graph_ = !(e && e[0] == '1');
-    e = std::getenv("KKT_PERSISTENT");
+    e = S_.opt("persistent");
     use_programs_ = !(e && e[0] == '0');
     // opt-in: measured 0-3 % on cfg 2 (both lanes slow down when they share the chip, and the
     // smaller batches of a chunk are less efficient), DESIGN.md section 6
-    e = std::getenv("KKT_LANES");
+    e = S_.opt("lanes");
     use_lanes_ = e && e[0] == '1';
     build();
 }
@@ -117,7 +117,7 @@ void SchurPC::fuse_programs() {
     const Pattern &P = S_.patterns[m_pat_];
     if (!d_dep_) {
         int wpw = 0, nwg = 0;
-        const char *pm0 = std::getenv("KKT_PROG_MODE");
+        const char *pm0 = S_.opt("prog_mode");
         const bool try_g0 = !(pm0 && pm0[0] == 'f') && row_program_g_available(P.R, P.uniform_w);
         // the data-flow form for any width (matrix re-read from L2 every phase) is opt-in
         // (KKT_PROG_MODE=w): re-polling whole chunks of granules costs more fabric traffic
@@ -127,7 +127,7 @@ void SchurPC::fuse_programs() {
         const bool try_g = !try_gw && try_g0;
         // data-flow form: one wave per workgroup (no workgroup barrier on the critical path)
         // while all of them are co-resident; else 4 / 8 waves per workgroup
-        const char *pw = std::getenv("KKT_PROG_WAVES");
+        const char *pw = S_.opt("prog_waves");
         const int first = pw ? std::atoi(pw) : (try_g ? 1 : 4);
         int n_cus = 0, dev_id = 0;
         if (hipGetDevice(&dev_id) != hipSuccess ||
@@ -202,7 +202,7 @@ void SchurPC::fuse_programs() {
         }
         // data-flow form: needs the exact gather relation between workgroups to be symmetric
         {
-            const char *pm = std::getenv("KKT_PROG_MODE");
+            const char *pm = S_.opt("prog_mode");
             const bool gw_ok = pm && pm[0] == 'w' && P.R == 2 &&
                                nwg <= row_program_gw_max_wgs(wpw);
             const bool g_ok = !gw_ok && row_program_g_available(P.R, P.uniform_w) &&
@@ -241,7 +241,7 @@ void SchurPC::fuse_programs() {
         }
         prog_wpw_ = wpw;
         prog_nwg_ = nwg;
-        if (std::getenv("KKT_VERBOSE"))
+        if (S_.opt("verbose"))
             std::fprintf(stderr, "[kkt] sweep program: mode %d (0 counters, 1 data-flow, 2 data-flow "
                          "any width), %d workgroups x %d waves, %d slices\n",
                          prog_mode_, nwg, wpw, P.nslices);
@@ -286,10 +286,8 @@ void SchurPC::fuse_programs() {
                 // compact records: Chebyshev steps that only continue the previous phase's
                 // solve are marked STEP (kernels.hpp, PhaseLite)
                 std::vector<PhaseLite> lite(ops.size());
-                static const bool use_steps = [] {
-                    const char *e = std::getenv("KKT_PROG_STEPS");
-                    return !(e && e[0] == '0');
-                }();
+                const char *ps = S_.opt("prog_steps");
+                const bool use_steps = !(ps && ps[0] == '0');
                 auto same = [](const VRef &a, const VRef &b) {
                     return a.base == b.base && (a.base < 0 || a.off == b.off);
                 };
@@ -471,18 +469,14 @@ void SchurPC::push_rows(std::vector<RowOp> &r) {
     s.rows.R = P.R;
     s.rows.uniform_w = P.uniform_w;
     s.rows.d_ops = dev_upload(r.data(), r.size());
-    static const bool kernarg_ops = [] {
-        const char *e = std::getenv("KKT_KERNARG_OPS");
-        return e && e[0] == '1';
-    }();
+    const char *ko = S_.opt("kernarg_ops");
+    const bool kernarg_ops = ko && ko[0] == '1';
     if (r.size() == 1) {
         s.rows.single = kernarg_ops;
         s.rows.h_op = r[0];
     }
-    static const bool use_shared = [] {
-        const char *e = std::getenv("KKT_SHARED_ROWS");
-        return !(e && e[0] == '0');
-    }();
+    const char *sr = S_.opt("shared_rows");
+    const bool use_shared = !(sr && sr[0] == '0');
     s.rows.shared_matrix = use_shared && r.size() >= 4;
     for (const RowOp &op : r)
         s.rows.shared_matrix = s.rows.shared_matrix && op.nterms == 1 &&
@@ -675,7 +669,7 @@ void SchurPC::build_BE() {
     const bool lanes = use_lanes_ && !S_.sharded && (hi - lo) >= 16;
     int n_chunks = 1;
     if (lanes) {
-        const char *e = std::getenv("KKT_LANE_CHUNKS");
+        const char *e = S_.opt("lane_chunks");
         n_chunks = std::max(2, std::min((hi - lo) / 4, e ? std::atoi(e) : 4));
     }
     std::vector<int> cfirst(n_chunks + 1);

@@ -4,6 +4,7 @@
 #include "system.hpp"
 
 #include <algorithm>
+#include <cctype>
 #include <cstdlib>
 #include <cstring>
 
@@ -19,6 +20,14 @@ void hip_check(hipError_t e, const char *what, const char *file, int line) {
         fail(KKT_ERR_HIP, std::string(hipGetErrorString(e)) + " in " + what + " at " + file +
                               ":" + std::to_string(line));
     }
+}
+
+const char *System::opt(const char *key) const {
+    auto it = options.find(key);
+    if (it != options.end()) return it->second.c_str();
+    std::string env = "KKT_";
+    for (const char *c = key; *c; ++c) env.push_back((char)std::toupper((unsigned char)*c));
+    return std::getenv(env.c_str());
 }
 
 System::~System() {
@@ -88,7 +97,7 @@ void System::set_layout(int n_blocks_00, int n_blocks_11, int64_t nx0_, int64_t 
     n1_loc = n1;
     nullspaces.assign(n0 + n1, NullspaceSpec{});
     layout_set = true;
-    const char *e = std::getenv("KKT_SELL_R");
+    const char *e = opt("sell_r");
     if (e && (e[0] == '1' || e[0] == '2')) sell_R = e[0] - '0';
 }
 
@@ -191,7 +200,7 @@ int System::find_or_add_pattern(int64_t nrows, int64_t ncols, const int32_t *ind
     // slots: sort the rows of every window of 8 slices by length (SELL-C-sigma) when that
     // saves at least 10 % of the storage.  Vectors keep their order; kernels reach the row
     // of a position through `perm`.
-    const char *sort_env = std::getenv("KKT_SELL_SORT");   // read per pattern: tests toggle it
+    const char *sort_env = opt("sell_sort");   // read per pattern: tests toggle it
     const bool allow_sort = !(sort_env && sort_env[0] == '0');
     if (allow_sort && nnz > 0) {
         const int64_t npos = (int64_t)P.nslices * C, sigma = 8 * (int64_t)C;
@@ -285,6 +294,13 @@ void System::add_block(int q, int i, int j, int64_t nrows, int64_t ncols,
     if (sharded) {
         if (i < lo || i >= hi) fail(KKT_ERR_ARG, "block row not owned by this rank");
         if (j < lo - 1 || j > hi) fail(KKT_ERR_ARG, "time sharding needs |i - j| <= 1 blocks");
+        // one halo per column variable is exchanged: x0 of block lo-1 and x1 of block hi
+        // (comm_exchange_x_halos) -- the couplings of the BE / CN stencils, control.py:2909-2953
+        const bool col0 = q == KKT_Q00 || q == KKT_Q10;
+        if (col0 && j == hi)
+            fail(KKT_ERR_ARG, "time sharding: a block of column variable 0 may reach block lo-1, not hi");
+        if (!col0 && j == lo - 1)
+            fail(KKT_ERR_ARG, "time sharding: a block of column variable 1 may reach block hi, not lo-1");
     }
     auto key = std::make_tuple(q, i, j);
     if (blocks.count(key)) fail(KKT_ERR_ARG, "block added twice");
@@ -366,6 +382,20 @@ void System::finalize() {
     info.n_local = n_local;
     info.n_patterns = (int64_t)patterns.size();
     info.bytes_algorithmic += 16 * n_local;
+    {
+        // what one apply must move when every value array and every index structure is read
+        // once (index arrays are shared between blocks of equal sparsity)
+        std::vector<char> va_used(values.size(), 0), pat_used(patterns.size(), 0);
+        for (auto &kv : blocks) va_used[kv.second.va] = 1;
+        info.bytes_streamed = 16 * n_local;
+        for (size_t v = 0; v < values.size(); ++v)
+            if (va_used[v]) {
+                info.bytes_streamed += 8 * patterns[values[v].pattern].nnz;
+                pat_used[values[v].pattern] = 1;
+            }
+        for (size_t q = 0; q < patterns.size(); ++q)
+            if (pat_used[q]) info.bytes_streamed += 4 * patterns[q].nnz + 4 * (patterns[q].nrows + 1);
+    }
 
     // ---- column masks: A P of the operator P A P + alpha (I - P) (preconditioner.py:95-103)
     {
@@ -475,6 +505,8 @@ void System::finalize() {
                         const Block *b = terms[t0];
                         const bool col0 = b->q == KKT_Q00 || b->q == KKT_Q10;
                         op.t[nt].vals = values[b->va].d_vals;
+                        block_term[std::make_tuple(b->q, b->i, b->j)] =
+                            std::make_tuple((int)w, waves.size() > w ? (int)waves[w].size() : 0, nt);
                         const int jl = sharded ? b->j - lo : b->j;
                         const int ncl = col0 ? n0_loc : n1_loc;
                         if (jl >= 0 && jl < ncl) {
@@ -529,6 +561,7 @@ void System::finalize() {
         L.d_ops = dev_upload(waves[w].data(), waves[w].size());
         apply_launches.push_back(L);
     }
+    h_apply_ops = waves;
 
     // ---- CN time transforms (preconditioner.py:437-525)
     if (CN) {
@@ -598,16 +631,59 @@ void System::update_block_values(int q, int i, int j, const double *vals) {
     if (!finalized) fail(KKT_ERR_STATE, "kkt_update_block_values needs a finalized system");
     auto it = blocks.find(std::make_tuple(q, i, j));
     if (it == blocks.end()) fail(KKT_ERR_ARG, "no such block");
-    ValueArray &va = values[it->second.va];
-    const Pattern &P = patterns[va.pattern];
+    Block &blk = it->second;
+    int users = 0;
+    for (auto &kv : blocks) users += kv.second.va == blk.va;
+    const int pat = values[blk.va].pattern;
+    const Pattern &P = patterns[pat];
     double *d_csr = dev_upload(vals, (size_t)P.nnz);
-    launch_csr_to_sell(stream, d_csr, P.d_sell2csr, va.d_vals, P.npadded);
-    if (va.colmask_set >= 0)
-        launch_mask_columns(stream, va.d_vals, P.d_col, bc_sets[va.colmask_set].d_mask, P.npadded);
+    auto fill = [&](double *dst, int colmask_set) {
+        launch_csr_to_sell(stream, d_csr, P.d_sell2csr, dst, P.npadded);
+        if (colmask_set >= 0)
+            launch_mask_columns(stream, dst, P.d_col, bc_sets[colmask_set].d_mask, P.npadded);
+    };
+    if (users <= 1) {
+        fill(values[blk.va].d_vals, values[blk.va].colmask_set);
+        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipFree(d_csr));
+        pc_stale = true;
+        return;
+    }
+    // The value array is shared with other blocks (same object at construction): the
+    // reference re-assembles every block on its own, so an update must not reach the sharers.
+    // Identical values (a Picard loop re-sending its mass couplings) change nothing; new
+    // values give this block a private array (copy on write) and its RowOp term is re-pointed.
+    double *d_new = dev_alloc<double>(P.npadded);
+    fill(d_new, values[blk.va].colmask_set);
+    unsigned *d_flag = dev_alloc<unsigned>(1);
+    HIPCHK(hipMemsetAsync(d_flag, 0, sizeof(unsigned), stream));
+    launch_vals_differ(stream, d_new, values[blk.va].d_vals, P.npadded, d_flag);
+    unsigned differ = 0;
+    HIPCHK(hipMemcpyAsync(&differ, d_flag, sizeof differ, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipFree(d_flag));
     HIPCHK(hipFree(d_csr));
-    // the preconditioner's matrices are sums with block values: rebuilt lazily, once, at the
-    // next application (a Picard iteration updates hundreds of blocks in a row)
+    if (!differ) {
+        HIPCHK(hipFree(d_new));
+        return;
+    }
+    ValueArray c = values[blk.va];
+    const double *d_old = c.d_vals;
+    c.d_vals = d_new;
+    c.share_id = -1;
+    values.push_back(c);
+    blk.va = (int)values.size() - 1;
+    info.bytes_device_values += P.npadded * 8;
+    info.n_value_arrays++;
+    info.bytes_algorithmic += 12 * P.nnz + 4 * (P.nrows + 1);
+    info.bytes_streamed += 8 * P.nnz;
+    auto loc = block_term.find(std::make_tuple(q, i, j));
+    if (loc == block_term.end()) fail(KKT_ERR_STATE, "block missing from the apply plan");
+    const int L = std::get<0>(loc->second), o = std::get<1>(loc->second), t = std::get<2>(loc->second);
+    RowOp &op = h_apply_ops[L][o];
+    if (op.t[t].vals != d_old) fail(KKT_ERR_STATE, "apply plan out of step with the block table");
+    op.t[t].vals = d_new;
+    HIPCHK(hipMemcpy(apply_launches[L].d_ops + o, &op, sizeof(RowOp), hipMemcpyHostToDevice));
     pc_stale = true;
 }
 

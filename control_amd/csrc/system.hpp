@@ -145,6 +145,9 @@ struct System {
 
     // apply plan
     std::vector<RowLaunch> apply_launches;
+    std::vector<std::vector<RowOp>> h_apply_ops;   // host copies (value pointers are re-pointed
+                                                   // when an update un-shares a value array)
+    std::map<std::tuple<int, int, int>, std::tuple<int, int, int>> block_term;   // -> launch, op, term
     std::vector<TimeGroup> time_groups;
     bool fused_row_masks = false;     // Dirichlet epilogue fused into the row kernel
     bool any_const_ns = false;
@@ -175,6 +178,10 @@ struct System {
     std::unique_ptr<Comm> comm;
 
     KrylovCfg ksp;
+    // execution options (kkt_set_option); a key that was never set falls back to the
+    // environment variable KKT_<KEY> (developer scripts), then to the built-in default
+    std::map<std::string, std::string> options;
+    const char *opt(const char *key) const;
     // Krylov workspace (lazily sized)
     int ws_restart = 0;
     bool ws_flexible = false;

@@ -188,7 +188,8 @@ class MultiBlockSystem:
     def __init__(self, space_0, space_1, block_00, block_01, block_10, block_11, *,
                  n_blocks_00=1, n_blocks_11=1, sub_n_blocks_00_0=None,
                  sub_n_blocks_11_0=None, nullspace_0=None, nullspace_1=None,
-                 form_compiler_parameters=None, CN=False, device=0, comm=None):
+                 form_compiler_parameters=None, CN=False, device=0, comm=None, options=None,
+                 share_values=True):
         if nullspace_0 is None:
             nullspace_0 = tuple(NoneNullspace() for _ in range(n_blocks_00))
         if nullspace_1 is None:
@@ -212,6 +213,8 @@ class MultiBlockSystem:
         self._CN = bool(CN)
         self._comm = comm
         self._cb_keep = []
+        for key, value in (options or {}).items():     # kernel-form switches (kkt_set_option)
+            self.set_option(key, value)
         self._ck(self._lib.kkt_set_layout(
             self._h, n_blocks_00, n_blocks_11, nx0, nx1, int(bool(CN)),
             -1 if sub_n_blocks_00_0 is None else int(sub_n_blocks_00_0),
@@ -239,7 +242,9 @@ class MultiBlockSystem:
                 nrows = len(indptr) - 1
                 ncols = nx0 if q in (Q00, Q10) else nx1
                 # the same Python object given for several (i, j) shares device storage
-                sid = share_ids.setdefault(id(A), len(share_ids))
+                # (share_values=False: every block gets its own device copy -- "mode G", what
+                # the reference stores -- even when the host objects are shared)
+                sid = share_ids.setdefault(id(A), len(share_ids)) if share_values else -1
                 # the index array is kept referenced, so its address identifies it for good
                 self._structure[(q, i, j)] = [len(data), None, indices]   # hash: on first need
                 self._ck(self._lib.kkt_add_block(
@@ -285,6 +290,11 @@ class MultiBlockSystem:
     @property
     def local_size(self):
         return self._n0_loc * self._nx0 + self._n1_loc * self._nx1
+
+    def set_option(self, key, value):
+        """``kkt_set_option``: which kernel form runs (include/kkt.h lists the keys)."""
+        self._ck(self._lib.kkt_set_option(self._h, str(key).encode(), str(value).encode()))
+        self._pc_state = None if key != "verbose" else getattr(self, "_pc_state", None)
 
     def info(self):
         inf = _lib.Info()

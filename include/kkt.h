@@ -69,6 +69,25 @@ int kkt_destroy(kkt_handle h);
 /* Message of the last failing call on `h` (or of the last failing kkt_create if NULL). */
 const char *kkt_last_error(kkt_handle h);
 
+/* Execution options: which kernel form runs, not what is computed (every form of a step
+ * performs the same arithmetic in the same order; tests toggle them to assert that).  Set a
+ * key before the call that reads it: storage keys before kkt_set_layout / kkt_add_block,
+ * preconditioner keys before kkt_set_pc_schur.  Unknown keys are rejected.
+ *   "sell_r"      "1" | "2"      rows per lane of the SELL-64R storage (default 2)
+ *   "sell_sort"   "0" | "1"      row-sorted storage for ragged structures (default 1)
+ *   "no_graph"    "1"            replay the preconditioner as plain launches, no hipGraph
+ *   "persistent"  "0"            time sweeps as one launch per step (no sweep programs)
+ *   "prog_mode"   "tile" | "flow" | "flags" | "w"   sweep-program form (default: the fastest
+ *                                that fits: tile, else flow, else flags)
+ *   "prog_waves"  "1".."8"       waves per workgroup of the flow / flags forms
+ *   "prog_steps"  "0"            flow form without compact STEP records
+ *   "tile_depth"  "1".."16"      Chebyshev steps per hand-off of the tile form
+ *   "tile_waves"  "4" | "8" | "16"   waves per workgroup of the tile form
+ *   "lanes", "lane_chunks", "kernarg_ops", "shared_rows", "verbose"   diagnostics
+ * A key that was never set falls back to the environment variable KKT_<KEY> (developer
+ * scripts), then to the default. */
+int kkt_set_option(kkt_handle h, const char *key, const char *value);
+
 /* ------------------------------------------------------------------ definition */
 
 /* Block counts and spatial sizes (preconditioner.py:217-222, 276-302).
@@ -239,6 +258,9 @@ typedef struct kkt_info {
     int64_t bytes_algorithmic;  /* sum_unique[12 nnz + 4(rows+1)] + 16 N */
     int64_t bytes_device_values;/* padded value bytes actually resident */
     int64_t bytes_device_index; /* padded index bytes actually resident */
+    int64_t bytes_streamed;     /* bytes one kkt_apply must move with what is stored once read
+                                   once: sum over value arrays 8 nnz + sum over sparsity
+                                   structures [4 nnz + 4 (rows + 1)] + 16 N */
     double last_solve_ms;       /* wall time of the last kkt_solve* Krylov loop */
     int64_t last_pc_applies;    /* preconditioner applications in the last solve */
     int64_t last_op_applies;    /* operator applications in the last solve */

@@ -245,8 +245,8 @@ int ref_gmres_BE(const ref_sys_t *S, const ref_pc_t *P, const double *b_in, doub
         if (msk) x[p] = 0.0;
     }
     ref_pc_apply_BE(P, b, t2);
-    const double rnorm0 = sqrt(dotp(t2, t2, N));
-    const double ttol = fmax(rtol * rnorm0, atol);
+    double rnorm0 = sqrt(dotp(t2, t2, N));
+    double ttol = fmax(rtol * rnorm0, atol);
     int its = 0, reason = 0, nh = 0;
     double rn = 0.0;
 #define LOG(v)                        \
@@ -260,6 +260,10 @@ int ref_gmres_BE(const ref_sys_t *S, const ref_pc_t *P, const double *b_in, doub
         for (int64_t p = 0; p < N; ++p) t2[p] = b[p] - t1[p];
         ref_pc_apply_BE(P, t2, V);
         rn = sqrt(dotp(V, V, N));
+        if (rnorm0 == 0.0) { /* KSPConvergedDefault: zero right-hand side, non-zero guess */
+            rnorm0 = rn;
+            ttol = fmax(rtol * rn, atol);
+        }
         LOG(rn);
         if (rn == 0.0) {
             reason = 3;

@@ -183,6 +183,7 @@ class _ConvergedDefault:
     """``KSPConvergedDefault`` with the RHS norm as ``rnorm0`` (nonzero initial guess)."""
 
     def __init__(self, rtol, atol, divtol, rnorm0):
+        self.rtol = rtol
         self.atol = atol
         self.divtol = divtol
         self.rnorm0 = rnorm0
@@ -191,6 +192,10 @@ class _ConvergedDefault:
     def __call__(self, rnorm):
         if not np.isfinite(rnorm):
             return DIVERGED_NANORINF
+        if self.rnorm0 == 0.0:
+            # KSPConvergedDefault, "special case of zero RHS and nonzero guess": snorm = rnorm
+            self.rnorm0 = rnorm
+            self.ttol = max(self.rtol * rnorm, self.atol)
         if rnorm <= self.ttol:
             return CONVERGED_ATOL if rnorm < self.atol else CONVERGED_RTOL
         if rnorm >= self.divtol * self.rnorm0:

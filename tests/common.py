@@ -1,25 +1,8 @@
 """Shared builders for the parity tests: one problem -> (oracle system, GPU system)."""
 import numpy as np
 
-from control_amd.blocks import instationary_blocks, stationary_blocks
-from control_amd.fem import unit_cube_p1, unit_square_p1, unit_square_q2
-
-SEED = 20241008
-
-
-def heat_problem(space="p1", n=10, n_t=10, beta=1.0e-4, T=2.0, CN=False, share=True,
-                 time_dependent=False):
-    """Config-1-shaped synthetic heat-control system (README example sizes by default)."""
-    sd = {"p1": unit_square_p1, "q2": unit_square_q2, "p1_3d": unit_cube_p1}[space](n)
-    tau = T / (n_t - 1.0)
-    if time_dependent:
-        # a forward operator that differs per time level (what Picard/NS produces): mode G
-        K = [sd.K + (0.1 * i) * sd.M for i in range(n_t)]
-    else:
-        K = sd.K
-    b00, b01, b10, b11, m = instationary_blocks(sd.M, K, tau, beta, n_t, CN, share=share)
-    return dict(sd=sd, tau=tau, beta=beta, n_t=n_t, CN=CN, m=m,
-                blocks=(b00, b01, b10, b11), nodes=sd.boundary)
+from control_amd.problems import (SEED, STOKES_SPECS, gpu_pc, gpu_system, heat_problem,  # noqa: F401
+                                  rng_vector, stokes_gpu, stokes_problem)
 
 
 def oracle_system(p):
@@ -28,14 +11,6 @@ def oracle_system(p):
     ns = tuple(ko.DirichletBCNullspace(p["nodes"]) for _ in range(m))
     return ko.OracleSystem(sd.n_dofs, sd.n_dofs, *p["blocks"], n_blocks_00=m,
                            n_blocks_11=m, nullspace_0=ns, nullspace_1=ns, CN=p["CN"])
-
-
-def gpu_system(p, **kw):
-    from control_amd.multiblock import DirichletBCNullspace, MultiBlockSystem
-    sd, m = p["sd"], p["m"]
-    ns = tuple(DirichletBCNullspace(p["nodes"]) for _ in range(m))
-    return MultiBlockSystem(sd.n_dofs, sd.n_dofs, *p["blocks"], n_blocks_00=m,
-                            n_blocks_11=m, nullspace_0=ns, nullspace_1=ns, CN=p["CN"], **kw)
 
 
 def oracle_pc(p, mass, schur):
@@ -47,36 +22,12 @@ def oracle_pc(p, mass, schur):
              ko.ChebSpec(*mass), ko.ChebSpec(*schur))
 
 
-def gpu_pc(p, mass, schur):
-    from control_amd.multiblock import ChebSpec, SchurPC
-    return SchurPC(kind="CN" if p["CN"] else "BE", M=p["sd"].M, beta=p["beta"],
-                   bc_nodes=p["nodes"], mass=ChebSpec(*mass), schur=ChebSpec(*schur),
-                   n_t=p["n_t"], tau=p["tau"])
-
-
-def rng_vector(n, seed=SEED):
-    return np.random.default_rng(seed).standard_normal(n)
-
-
 def rel_err(a, b):
     return np.linalg.norm(np.ravel(a) - np.ravel(b)) / max(np.linalg.norm(np.ravel(b)), 1e-300)
 
 
 # ------------------------------------------ instationary Stokes control
 
-STOKES_SPECS = dict(mass=(20, 0.3, 1.9), schur=(30, 0.02, 2.2), kp=(30, 0.02, 2.2),
-                    mp=(20, 0.25, 2.25))
-
-
-def stokes_problem(n=4, n_t=4, beta=1.0e-2, T=2.0, CN=False, share=True):
-    """Config-3-shaped system: P2-P1 on ``RectangleMesh(n, n, 2, 2)`` (BASELINE configs[2])."""
-    from control_amd.blocks import instationary_incompressible_blocks
-    from control_amd.fem import rectangle_p2p1
-    th = rectangle_p2p1(n, n, 2.0, 2.0)
-    tau = T / (n_t - 1.0)
-    bl = instationary_incompressible_blocks(th.M_v, th.K_v, th.B, th.M_p, th.K_p, tau, beta,
-                                            n_t, CN, share=share)
-    return dict(th=th, tau=tau, beta=beta, n_t=n_t, CN=CN, m=bl["m"], blocks=bl)
 
 
 def stokes_oracle(p, specs=STOKES_SPECS):
@@ -93,30 +44,6 @@ def stokes_oracle(p, specs=STOKES_SPECS):
         p["beta"], th.boundary_v, ko.ChebSpec(*specs["mass"]), ko.ChebSpec(*specs["schur"]),
         ko.ChebSpec(*specs["kp"]), ko.ChebSpec(*specs["mp"]), CN=CN)
     return osys, opc
-
-
-def stokes_gpu(p, specs=STOKES_SPECS):
-    """Outer system, velocity KKT system and pressure commutator on the GPU + the StokesPC."""
-    from control_amd.multiblock import (ChebSpec, ConstantNullspace, DirichletBCNullspace,
-                                        MultiBlockSystem, SchurPC, StokesPC)
-    th, m, CN, bl = p["th"], p["m"], p["CN"], p["blocks"]
-    nsv = DirichletBCNullspace(th.boundary_v)
-    kw = dict(sub_n_blocks_00_0=m, sub_n_blocks_11_0=m) if CN else {}
-    outer = MultiBlockSystem(th.n_v, th.n_p, *bl["outer"], n_blocks_00=2 * m,
-                             n_blocks_11=2 * m, nullspace_0=(nsv,) * (2 * m),
-                             nullspace_1=tuple(ConstantNullspace() for _ in range(2 * m)),
-                             CN=CN, **kw)
-    inner = MultiBlockSystem(th.n_v, th.n_v, *bl["inner"], n_blocks_00=m, n_blocks_11=m,
-                             nullspace_0=(nsv,) * m, nullspace_1=(nsv,) * m, CN=CN)
-    # the commutator product is a plain block product (control.py:4625-4665): no transforms
-    comm = MultiBlockSystem(th.n_p, th.n_p, *bl["commutator"], n_blocks_00=m, n_blocks_11=m)
-    inner_pc = SchurPC(kind="CN" if CN else "BE", M=th.M_v, beta=p["beta"],
-                       bc_nodes=th.boundary_v, mass=ChebSpec(*specs["mass"]),
-                       schur=ChebSpec(*specs["schur"]), n_t=p["n_t"], tau=p["tau"])
-    gpc = StokesPC(inner=inner, inner_pc=inner_pc, commutator=comm, B=th.B, K_p=th.K_p,
-                   M_p=th.M_p, kp=ChebSpec(*specs["kp"]), mp=ChebSpec(*specs["mp"]),
-                   n_p_blocks=m, b_scale=p["tau"], post_scale=1.0 / p["tau"]**2, cn=CN)
-    return outer, gpc
 
 
 # ------------------------------------------ Navier-Stokes control, Picard loop (SURVEY 8f-2)

@@ -2,8 +2,6 @@
 (generic-width kernels), rectangular blocks, ConstantNullspace and FullNullspace, mixed
 boundary sets (automatic un-sharing of value arrays), the CN sub-block split, value
 updates, argument errors."""
-import os
-
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -33,7 +31,7 @@ def ragged(n_rows, n_cols, seed, density=0.02, empty_every=7, heavy_every=50):
 def pair(nx0, nx1, blocks, n0, n1, ns0, ns1, ons0, ons1, **kw):
     g = MultiBlockSystem(nx0, nx1, *blocks, n_blocks_00=n0, n_blocks_11=n1, nullspace_0=ns0,
                          nullspace_1=ns1, **kw)
-    okw = {k: v for k, v in kw.items() if k != "device"}
+    okw = {k: v for k, v in kw.items() if k not in ("device", "options")}
     o = ko.OracleSystem(nx0, nx1, *blocks, n_blocks_00=n0, n_blocks_11=n1, nullspace_0=ons0,
                         nullspace_1=ons1, **okw)
     return g, o
@@ -43,45 +41,41 @@ def pair(nx0, nx1, blocks, n0, n1, ns0, ns1, ons0, ons1, **kw):
 def test_ragged_rectangular_blocks_with_mixed_nullspaces(sell_r):
     """2 + 3 blocks of different sizes, rectangular couplings, every nullspace kind, empty
     rows, rows of 40 entries among rows of 3 (no uniform width -> generic kernels)."""
-    os.environ["KKT_SELL_R"] = sell_r
-    try:
-        nx0, nx1, n0, n1 = 301, 157, 2, 3
-        b00 = {(i, j): None for i in range(n0) for j in range(n0)}
-        b01 = {(i, j): None for i in range(n0) for j in range(n1)}
-        b10 = {(i, j): None for i in range(n1) for j in range(n0)}
-        b11 = {(i, j): None for i in range(n1) for j in range(n1)}
-        b00[(0, 0)] = ragged(nx0, nx0, 1)
-        b00[(1, 0)] = ragged(nx0, nx0, 2)
-        b00[(1, 1)] = b00[(0, 0)]                      # shared object
-        b01[(0, 1)] = ragged(nx0, nx1, 3)
-        b01[(1, 2)] = ragged(nx0, nx1, 4)
-        b10[(0, 0)] = ragged(nx1, nx0, 5)
-        b10[(2, 1)] = ragged(nx1, nx0, 6)
-        b11[(1, 1)] = ragged(nx1, nx1, 7)
-        b11[(2, 0)] = ragged(nx1, nx1, 8)               # block row 0 of variable 1 has no 11 term
-        bc0 = np.array([0, 5, 17, 300])
-        bc1 = np.array([1, 2, 156])
-        g, o = pair(nx0, nx1, (b00, b01, b10, b11), n0, n1,
-                    (DirichletBCNullspace(bc0, alpha=2.5), NoneNullspace()),
-                    (ConstantNullspace(alpha=0.5), DirichletBCNullspace(bc1), FullNullspace()),
-                    (ko.DirichletBCNullspace(bc0, alpha=2.5), ko.NoneNullspace()),
-                    (ko.ConstantNullspace(alpha=0.5), ko.DirichletBCNullspace(bc1),
-                     ko.FullNullspace()))
-        for seed in range(3):
-            x = common.rng_vector(o.N, 100 + seed)
-            assert common.rel_err(g.mult(x), o.mult(x)) < 1e-13
+    nx0, nx1, n0, n1 = 301, 157, 2, 3
+    b00 = {(i, j): None for i in range(n0) for j in range(n0)}
+    b01 = {(i, j): None for i in range(n0) for j in range(n1)}
+    b10 = {(i, j): None for i in range(n1) for j in range(n0)}
+    b11 = {(i, j): None for i in range(n1) for j in range(n1)}
+    b00[(0, 0)] = ragged(nx0, nx0, 1)
+    b00[(1, 0)] = ragged(nx0, nx0, 2)
+    b00[(1, 1)] = b00[(0, 0)]                      # shared object
+    b01[(0, 1)] = ragged(nx0, nx1, 3)
+    b01[(1, 2)] = ragged(nx0, nx1, 4)
+    b10[(0, 0)] = ragged(nx1, nx0, 5)
+    b10[(2, 1)] = ragged(nx1, nx0, 6)
+    b11[(1, 1)] = ragged(nx1, nx1, 7)
+    b11[(2, 0)] = ragged(nx1, nx1, 8)               # block row 0 of variable 1 has no 11 term
+    bc0 = np.array([0, 5, 17, 300])
+    bc1 = np.array([1, 2, 156])
+    g, o = pair(nx0, nx1, (b00, b01, b10, b11), n0, n1,
+                (DirichletBCNullspace(bc0, alpha=2.5), NoneNullspace()),
+                (ConstantNullspace(alpha=0.5), DirichletBCNullspace(bc1), FullNullspace()),
+                (ko.DirichletBCNullspace(bc0, alpha=2.5), ko.NoneNullspace()),
+                (ko.ConstantNullspace(alpha=0.5), ko.DirichletBCNullspace(bc1),
+                 ko.FullNullspace()), options={"sell_r": sell_r})
+    for seed in range(3):
+        x = common.rng_vector(o.N, 100 + seed)
+        assert common.rel_err(g.mult(x), o.mult(x)) < 1e-13
 
-        def pc(u_0, u_1, b_0, b_1):
-            u_0[:] = 3.0 * b_0
-            u_1[:] = b_1[::-1]
-        x = common.rng_vector(o.N, 7)
-        assert common.rel_err(g.pc_apply(x, pc), o.pc_apply(pc, x)) < 1e-14
-        assert common.rel_err(g.pc_apply(x, None),
-                              o.pc_apply(lambda a, b, c, d: (a.__setitem__(slice(None), c),
-                                                             b.__setitem__(slice(None), d)),
-                                         x)) < 1e-14
-    finally:
-        del os.environ["KKT_SELL_R"]
+    def pc(u_0, u_1, b_0, b_1):
+        u_0[:] = 3.0 * b_0
+        u_1[:] = b_1[::-1]
+    x = common.rng_vector(o.N, 7)
+    assert common.rel_err(g.pc_apply(x, pc), o.pc_apply(pc, x)) < 1e-14
+    assert common.rel_err(g.pc_apply(x, None),
+                          o.pc_apply(lambda a, b, c, d: (a.__setitem__(slice(None), c),
+                                                         b.__setitem__(slice(None), d)),
+                                     x)) < 1e-14
 
 
 def test_shared_values_with_different_boundary_sets_are_unshared():
@@ -226,16 +220,15 @@ def test_full_size_solve_reduces_true_residual_and_is_reproducible():
     assert abs(h[-1] - res) < 1e-6 * h[0]                      # monitored norm is the true one
 
 
-def test_row_sorted_storage_is_bit_identical(monkeypatch):
+def test_row_sorted_storage_is_bit_identical():
     """Structures with rows of very different lengths (P2: 9 or 19 non-zeros) are stored
     row-sorted inside windows of 8 slices (SELL-C-sigma); every row keeps its own fma chain,
     so operator and preconditioner are bit-identical to the unsorted storage -- with fewer
     padded slots."""
     outs, infos = [], []
     for flag in ("0", "1"):
-        monkeypatch.setenv("KKT_SELL_SORT", flag)
         p = common.stokes_problem(n=8, n_t=4)
-        outer, gpc = common.stokes_gpu(p)
+        outer, gpc = common.stokes_gpu(p, options={"sell_sort": flag})
         x = common.rng_vector(outer.info()["n_local"])
         outs.append((outer.mult(x), outer.pc_apply(x, gpc)))
         infos.append(outer.info())
@@ -244,7 +237,7 @@ def test_row_sorted_storage_is_bit_identical(monkeypatch):
     assert infos[1]["bytes_device_values"] < 0.85 * infos[0]["bytes_device_values"]
 
 
-def test_mid_size_mesh_long_sweep_program_matches_plain_launches(monkeypatch):
+def test_mid_size_mesh_long_sweep_program_matches_plain_launches():
     """A mesh with more than 1 024 slices (401^2 nodes: 1 257) runs the data-flow sweep program
     with multi-wave workgroups; with 4-wave workgroups, two to a CU, programs of about 1 000
     phases timed out waiting for a neighbour (error -2).  The shapes in use -- one-wave
@@ -259,7 +252,6 @@ def test_mid_size_mesh_long_sweep_program_matches_plain_launches(monkeypatch):
     x = common.rng_vector(2 * p["m"] * p["sd"].n_dofs)
     g = common.gpu_system(p)
     y = g.pc_apply(x, common.gpu_pc(p, p["mass"], p["schur"]))
-    monkeypatch.setenv("KKT_PERSISTENT", "0")
-    g2 = common.gpu_system(p)
+    g2 = common.gpu_system(p, options={"persistent": "0"})
     y2 = g2.pc_apply(x, common.gpu_pc(p, p["mass"], p["schur"]))
     assert np.array_equal(y, y2)

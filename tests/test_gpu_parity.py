@@ -69,13 +69,11 @@ def test_preconditioner_parity_many_workgroups(CN):
     # same arithmetic in the same order: plain launches, the counter form and the data-flow
     # form of the persistent program agree exactly
     # ("w": the opt-in data-flow form for any row width, matrix re-read every phase)
-    for var, val in (("KKT_PERSISTENT", "0"), ("KKT_PROG_MODE", "flags"), ("KKT_PROG_MODE", "w")):
-        os.environ[var] = val
-        try:
-            other = common.gpu_system(p).pc_apply(x, common.gpu_pc(p, MASS, schur))
-        finally:
-            del os.environ[var]
-        assert np.array_equal(got, other), var
+    for var, val in (("persistent", "0"), ("prog_mode", "flags"), ("prog_mode", "w"),
+                     ("prog_mode", "flow"), ("prog_mode", "tile")):
+        other = common.gpu_system(p, options={var: val}).pc_apply(
+            x, common.gpu_pc(p, MASS, schur))
+        assert np.array_equal(got, other), (var, val)
 
 
 KRYLOV_SCHUR = (12, 0.08, 2.1)   # beta = 1e-2 on the 10x10 mesh: kappa(D^-1 S) ~ 25
