@@ -56,6 +56,11 @@ class Info(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class StepLock(C.Structure):
+    _fields_ = [("n_steps", C.c_int), ("restart", C.c_int), ("V", c_f64p), ("h", c_f64p),
+                ("v_next", c_f64p)]
+
+
 PC_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, c_f64p, c_f64p, c_f64p, c_f64p)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, c_f64p, C.c_int, C.c_int)
 SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, c_f64p, C.c_int64, C.c_int,
@@ -107,6 +112,7 @@ SIGNATURES = {
                                     C.POINTER(C.c_float)]),
     "kkt_time_pc_sweeps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float),
                                      C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "kkt_debug_set_steplock": (C.c_int, [C.c_void_p, C.POINTER(StepLock)]),
     "kkt_get_info": (C.c_int, [C.c_void_p, C.POINTER(Info)]),
     "kkt_comm_unique_id": (C.c_int, [C.c_void_p]),
     "kkt_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -68,7 +68,7 @@ int kkt_set_option(kkt_handle h, const char *key, const char *value) {
         static const char *known[] = {"sell_r", "sell_sort", "no_graph", "persistent", "prog_mode",
                                       "prog_waves", "prog_steps", "tile_depth", "tile_waves",
                                       "lanes", "lane_chunks", "kernarg_ops", "shared_rows",
-                                      "verbose"};
+                                      "verbose", "stamps", "tile_poll_delay"};
         if (!key || !value) fail(KKT_ERR_ARG, "null option");
         bool ok = false;
         for (const char *k : known) ok = ok || std::strcmp(k, key) == 0;
@@ -287,6 +287,18 @@ int kkt_time_pc_sweeps(kkt_handle h, const double *d_x, double *d_y, float *ms, 
     KKT_TRY(h, {
         if (!d_x || !d_y || !ms || !launches || !phases) fail(KKT_ERR_ARG, "null argument");
         S.pc_apply_timed(d_x, d_y, ms, launches, phases);
+    });
+}
+
+int kkt_debug_set_steplock(kkt_handle h, const kkt_steplock *lock) {
+    KKT_TRY(h, {
+        if (!lock) {
+            S.steplock = kkt_steplock{};
+        } else {
+            if (lock->n_steps < 1 || lock->restart < 1 || !lock->V || !lock->h || !lock->v_next)
+                fail(KKT_ERR_ARG, "incomplete step-lock description");
+            S.steplock = *lock;
+        }
     });
 }
 

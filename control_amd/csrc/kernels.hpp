@@ -91,6 +91,44 @@ void launch_row_program(hipStream_t s, const RowOp *d_ops, int nphases, int nwg,
                         int R, int uniform_w, const int32_t *d_dep, unsigned *d_flags,
                         unsigned *d_err);
 
+// ---- tile sweep program (tile_kernels.hip; plan: tiles.hpp)
+constexpr int TILE_DEPTH_MAX = 16;
+struct TileCoef { double c1, c2, c3; };
+// One time level of a sweep: optional update b = ca * (sum_t U_t x_prev) + cy * bin on the
+// boundary-masked rows, then `its` Jacobi-Chebyshev steps with the matrix `vals` on b, result in
+// `out` (control.py:2263-2295 / 2375-2406: "b_i += M u_{i-1}; solve").
+struct TileLevel {
+    const double *vals;        // SELL values of the level's matrix F_i
+    const double *dinv;        // its Jacobi diagonal, inverted (1 on boundary rows)
+    const double *bin;         // right-hand side before the update
+    double *bout;              // where the updated right-hand side is stored (may be bin; may be null)
+    double *out;               // u_i
+    const double *x_prev;      // the vector the update multiplies
+    const double *upd_vals[2]; // SELL values of the update terms
+    int32_t n_upd;             // 0: no update at this level
+    int32_t prev_in_lds;       // x_prev is the previous level's `out` (handed over inside the launch)
+    double ca, cy;
+    double p1_scale;           // first step: p_1 = p1_scale * dinv * b
+    double post1, post2;       // factors of the last step
+    const TileCoef *coef;      // steps 2 .. its: p_s = c1 p_{s-2} + c2 p_{s-1} + c3 dinv (b - F p_{s-1})
+};
+struct TileArgs {
+    int32_t nlevels, its, depth, nk_pad, rpt, W;
+    unsigned long long *gnew[2], *gold[2];   // granule buffers, 2 words per row each
+    unsigned granule_bytes;
+    unsigned *err;                            // word 0: error bits; words 8..: first time-out record
+    int32_t stamps;                           // diagnostics: per-tile 100 MHz tick sums at err + 64
+    int32_t poll_delay;                       // s_sleep units between publishing and the first poll
+};
+bool tile_sweep_available(int W, int rpt, int threads);
+size_t tile_sweep_lds_bytes(int nk_pad, int its);
+// workgroups of `threads` that are certainly co-resident (one per CU)
+int tile_sweep_max_tiles(int W, int rpt, int threads, size_t lds_bytes);
+void launch_tile_sweep(hipStream_t s, const TileArgs &a, const TileLevel *d_levels,
+                       const int32_t *d_n, const int32_t *d_grow, const uint16_t *d_lcol,
+                       const int32_t *d_gpos, const uint8_t *d_rowmask, int ntiles, int threads,
+                       size_t granule_words);
+
 // ---- value-array preparation
 void launch_csr_to_sell(hipStream_t s, const double *csr_vals, const int32_t *sell2csr,
                         double *sell_vals, int64_t n_padded);

@@ -366,6 +366,16 @@ void System::solve(const double *d_b, double *d_u, int *its_out, int *reason_out
         while (!reason && it < m && its < ksp.max_it) {
             if (it) log(rn);
             double *w = Vp(it + 1);
+            const bool locked = steplock.n_steps > 0 && its < steplock.n_steps;
+            if (locked) {
+                // step-locked parity: this step starts from the caller's basis
+                if (steplock.restart != m) fail(KKT_ERR_ARG, "step-lock restart differs from the KSP's");
+                const double *src = steplock.V + (size_t)its * (m + 1) * n_local;
+                for (int k = 0; k <= it; ++k)
+                    HIPCHK(hipMemcpyAsync(Vp(k), src + (size_t)k * n_local, n_local * 8,
+                                          hipMemcpyHostToDevice, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+            }
             if (right) {
                 double *z = flexible ? Zp(it) : d_t2;
                 pc_apply(Vp(it), z);
@@ -400,6 +410,13 @@ void System::solve(const double *d_b, double *d_u, int *its_out, int *reason_out
             const double hapbnd = std::min(std::fabs(tt / grs[it]), haptol);
             const bool hapend = tt < hapbnd;
             if (!hapend) launch_scale_inv(stream, w, w, d_tt, n_local);
+            if (locked) {
+                double *ho = steplock.h + (size_t)its * (m + 2);
+                for (int k = 0; k <= it + 1; ++k) ho[k] = h_pinned[k];
+                HIPCHK(hipMemcpyAsync(steplock.v_next + (size_t)its * n_local, w, n_local * 8,
+                                      hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+            }
             Hm(it + 1, it) = tt;
             // KSPGMRESUpdateHessenberg
             for (int j = 0; j < it; ++j) {

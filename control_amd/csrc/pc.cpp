@@ -54,6 +54,7 @@ SchurPC::SchurPC(System &S, const kkt_pc_desc &d) : S_(S), d_(d) {
 
 SchurPC::~SchurPC() {
     clear_program();
+    tile_plan_.release();
     for (hipEvent_t e : events_) (void)hipEventDestroy(e);
     if (side_) (void)hipStreamDestroy(side_);
     for (void *p : owned_)
@@ -71,6 +72,11 @@ void SchurPC::clear_program() {
             (void)hipFree(s.rows.d_ops);
     for (auto &s : steps_)
         if (s.d_lite) (void)hipFree(s.d_lite);
+    for (auto &s : steps_)
+        if (s.d_levels) (void)hipFree(s.d_levels);
+    for (void *p : tile_owned_) (void)hipFree(p);
+    tile_owned_.clear();
+    sweep_levels_.clear();
     steps_.clear();
     n_events_ = 0;
     cur_lane_ = 0;
@@ -110,12 +116,10 @@ void SchurPC::values_changed() {
     fuse_programs();
 }
 
-// Replace every run of >= 4 consecutive single-block steps (the time sweeps) by one
-// persistent launch with neighbour synchronisation (kernels.hip, pc_row_program).
-void SchurPC::fuse_programs() {
-    if (!use_programs_) return;
+// Shape and dependency tables of the row programs (counter and data-flow forms).
+bool SchurPC::setup_row_programs() {
     const Pattern &P = S_.patterns[m_pat_];
-    if (!d_dep_) {
+    {
         int wpw = 0, nwg = 0;
         const char *pm0 = S_.opt("prog_mode");
         const bool try_g0 = !(pm0 && pm0[0] == 'f') && row_program_g_available(P.R, P.uniform_w);
@@ -159,10 +163,7 @@ void SchurPC::fuse_programs() {
                 break;
             }
         }
-        if (!wpw) {
-            use_programs_ = false;
-            return;
-        }
+        if (!wpw) return false;
         // workgroup j must wait for every workgroup whose rows it gathers from, and for
         // every workgroup that gathers from its rows (write-after-read on rotating buffers)
         const int64_t rpw = (int64_t)wpw * 64 * P.R;
@@ -193,10 +194,7 @@ void SchurPC::fuse_programs() {
             }
         std::vector<int32_t> dep(2 * (size_t)nwg);
         for (int j = 0; j < nwg; ++j) {
-            if (shi[j] - slo[j] + 1 > 64) {   // one polling wave covers at most 64 neighbours
-                use_programs_ = false;
-                return;
-            }
+            if (shi[j] - slo[j] + 1 > 64) return false;   // one polling wave covers at most 64 neighbours
             dep[2 * j] = slo[j];
             dep[2 * j + 1] = shi[j];
         }
@@ -247,90 +245,222 @@ void SchurPC::fuse_programs() {
                          prog_mode_, nwg, wpw, P.nslices);
         d_dep_ = dev_upload(dep.data(), dep.size());
         d_flags_ = dev_alloc<unsigned>(prog_flag_words(nwg));
-        d_err_ = dev_alloc<unsigned>(64 + 16 * 1024);   // word 0: error bits; rest: debug stamps
-        HIPCHK(hipMemset(d_err_, 0, (64 + 16 * 1024) * sizeof(unsigned)));
         owned_.push_back(d_dep_);
         owned_.push_back(d_flags_);
+    }
+    return true;
+}
+
+// Tile plan and granule buffers of the tile sweep program (tile_kernels.hip), once per
+// preconditioner.  False when the structure does not fit (then the other forms run).
+bool SchurPC::prepare_tiles() {
+    if (tile_tried_) return tile_ok_;
+    tile_tried_ = true;
+    const Pattern &P = S_.patterns[m_pat_];
+    int n_cus = 0, dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess ||
+        hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess ||
+        n_cus < 1)
+        return false;
+    const char *tw = S_.opt("tile_waves");
+    const int threads = 64 * std::max(1, std::min(8, tw ? std::atoi(tw) : 8));
+    const char *td = S_.opt("tile_depth");
+    const int depth = td ? std::atoi(td) : 0;
+    // one workgroup per CU; tiny meshes get fewer tiles (at least 32 own rows each)
+    const int ntiles = (int)std::max<int64_t>(1, std::min<int64_t>(n_cus, P.nrows / 32));
+    if (!build_tile_plan(P, ntiles, depth, threads, 3, tile_plan_)) return false;
+    TilePlan &tp = tile_plan_;
+    if (!tp.symmetric || !tile_sweep_available(tp.W, tp.rpt, threads)) return false;
+    const size_t lds = tile_sweep_lds_bytes(tp.nk_pad, std::max(d_.schur_its, 2));
+    if (tp.ntiles > tile_sweep_max_tiles(tp.W, tp.rpt, threads, lds)) return false;
+    tp.upload();
+    const size_t words = 2 * (size_t)P.nrows;
+    for (int i = 0; i < 4; ++i) {
+        d_tg_[i] = dev_alloc<unsigned long long>(words);
+        owned_.push_back(d_tg_[i]);
+    }
+    if (S_.opt("verbose"))
+        std::fprintf(stderr, "[kkt] tile sweep program: %d tiles x %d threads, depth %d, W %d, "
+                     "%d row slots per thread; largest tile: %lld own rows, %lld computed rows, "
+                     "%lld ring rows; mean redundancy %.2f\n", tp.ntiles, threads, tp.depth, tp.W,
+                     tp.rpt, (long long)tp.max_own, (long long)tp.max_rows, (long long)tp.max_halo,
+                     tp.mean_redundancy);
+    tile_ok_ = true;
+    return true;
+}
+
+// Steps [k, e) are single-block steps: if they are exactly a run of recorded sweep levels the
+// tile form can express, replace them by one TILE step.
+bool SchurPC::fuse_tile_run(size_t k, size_t e, std::vector<PcStep> &out) {
+    std::vector<const SweepLevel *> run;
+    size_t cursor = k;
+    while (cursor < e) {
+        const SweepLevel *hit = nullptr;
+        for (const SweepLevel &lv : sweep_levels_)
+            if (lv.first == cursor) hit = &lv;
+        if (!hit || !hit->eligible || hit->last > e) return false;
+        run.push_back(hit);
+        cursor = hit->last;
+    }
+    if (run.empty()) return false;
+    const int its = run[0]->its;
+    std::vector<TileLevel> levels;
+    for (size_t i = 0; i < run.size(); ++i) {
+        const SweepLevel &lv = *run[i];
+        if (lv.its != its || (int)lv.coef.size() != its - 1) return false;
+        TileLevel L = lv.lev;
+        L.prev_in_lds = 0;
+        // operands read from plain memory must not be produced inside this launch
+        for (size_t j = 0; j < run.size(); ++j) {
+            const TileLevel &o = run[j]->lev;
+            if (L.bin == o.out || L.dinv == o.out) return false;
+            if (j != i && o.bout && (L.bin == o.bout)) return false;
+            if (L.n_upd > 0 && L.x_prev == o.out) {
+                if (j + 1 != i) return false;       // only the previous level's result is on chip
+                L.prev_in_lds = 1;
+            }
+            if (L.n_upd > 0 && o.bout && L.x_prev == o.bout) return false;
+        }
+        // identical coefficient tables share one device copy
+        TileCoef *d_coef = nullptr;
+        for (size_t j = 0; j < i && !d_coef; ++j)
+            if (run[j]->coef.size() == lv.coef.size() &&
+                std::memcmp(run[j]->coef.data(), lv.coef.data(), lv.coef.size() * sizeof(TileCoef)) == 0)
+                d_coef = const_cast<TileCoef *>(levels[j].coef);
+        if (!d_coef) {
+            d_coef = dev_upload(lv.coef.data(), lv.coef.size());
+            tile_owned_.push_back(d_coef);
+        }
+        L.coef = d_coef;
+        levels.push_back(L);
+    }
+    for (size_t q = k; q < e; ++q) (void)hipFree(steps_[q].rows.d_ops);
+    PcStep s;
+    s.kind = PcStep::TILE;
+    s.d_levels = dev_upload(levels.data(), levels.size());
+    s.nlevels = (int)levels.size();
+    s.its = its;
+    s.nphases = (int)(e - k);
+    out.push_back(s);
+    return true;
+}
+
+// Replace every run of >= 4 consecutive single-block steps (the time sweeps) by one
+// persistent launch: the tile form (tile_kernels.hip: `depth` steps per hand-off) where it
+// fits, else a row program with neighbour synchronisation (kernels.hip, pc_row_program*).
+void SchurPC::fuse_programs() {
+    if (!use_programs_) return;
+    if (!d_err_) {
+        d_err_ = dev_alloc<unsigned>(64 + 16 * 1024);   // word 0: error bits; rest: diagnostics
+        HIPCHK(hipMemset(d_err_, 0, (64 + 16 * 1024) * sizeof(unsigned)));
         owned_.push_back(d_err_);
+    }
+    const char *pm_all = S_.opt("prog_mode");
+    const bool tile_forced = pm_all && pm_all[0] == 't';
+    const bool tile_wanted = tile_forced || !pm_all || pm_all[0] == 'a';
+    const bool use_tiles = tile_wanted && prepare_tiles();
+    if (!legacy_tried_) {
+        legacy_tried_ = true;
+        legacy_ok_ = setup_row_programs();
+    }
+    if (!use_tiles && !legacy_ok_) {
+        use_programs_ = false;
+        return;
     }
     // output pointer the next phase may gather from
     auto gather_out = [](const RowOp &op) -> int64_t {
         return (op.mode == EPI_LIN && op.y2.base >= 0) ? op.y2.off : op.y.off;
     };
     std::vector<PcStep> out;
+    // one row program for the single-block steps [q0, q1)
+    auto emit_prog = [&](size_t q0, size_t q1) {
+        std::vector<RowOp> ops;
+        for (size_t q = q0; q < q1; ++q) {
+            ops.push_back(steps_[q].rows.h_op);
+            (void)hipFree(steps_[q].rows.d_ops);
+        }
+        PcStep s;
+        s.kind = PcStep::PROG;
+        s.rows.d_ops = dev_upload(ops.data(), ops.size());
+        s.nphases = (int)ops.size();
+        {
+            // compact records: Chebyshev steps that only continue the previous phase's
+            // solve are marked STEP (kernels.hpp, PhaseLite)
+            std::vector<PhaseLite> lite(ops.size());
+            const char *ps = S_.opt("prog_steps");
+            const bool use_steps = !(ps && ps[0] == '0');
+            auto same = [](const VRef &a, const VRef &b) {
+                return a.base == b.base && (a.base < 0 || a.off == b.off);
+            };
+            for (size_t e2 = 0; e2 < ops.size(); ++e2) {
+                const RowOp &op = ops[e2];
+                PhaseLite L{};
+                L.kind = 0;
+                if (use_steps && e2 >= 1) {
+                    const RowOp &pv = ops[e2 - 1];
+                    const bool has_pkm1 = op.pkm1.base >= 0;
+                    bool stepk = op.mode == EPI_CHEB && pv.mode == EPI_CHEB &&
+                                 op.nterms == 1 && pv.nterms == 1 &&
+                                 op.t[0].vals == pv.t[0].vals && op.col == pv.col &&
+                                 op.rowmask == pv.rowmask && op.dinv == pv.dinv &&
+                                 op.nslices == pv.nslices && op.nrows == pv.nrows &&
+                                 same(op.b, pv.b) && op.b.base == 0 && op.y.base == 0 &&
+                                 op.pk.base == 0 && same(op.pk, pv.y) &&
+                                 same(op.t[0].x, pv.y) &&
+                                 (!has_pkm1 || (pv.pk.base == 0 && same(op.pkm1, pv.pk)));
+                    if (stepk) {
+                        L.kind = 1;
+                        L.flags = has_pkm1 ? 1u : 0u;
+                        L.y = (uint64_t)op.y.off;
+                        L.c1 = op.c1;
+                        L.c2 = op.c2;
+                        L.c3 = op.c3;
+                        L.post1 = op.post1;
+                        L.post2 = op.post2;
+                    }
+                }
+                lite[e2] = L;
+            }
+            s.d_lite = dev_upload(lite.data(), lite.size());
+        }
+        s.granule = prog_granule_;
+        s.gmode = prog_mode_;
+        out.push_back(s);
+    };
     size_t k = 0;
     while (k < steps_.size()) {
         size_t e = k;
-        while (e < steps_.size() && steps_[e].kind == PcStep::ROWS && steps_[e].rows.nops == 1) {
-            if (prog_granule_ && e > k) {
-                // data-flow form: phase ph >= 1 gathers exactly what phase ph-1 produced
-                const RowOp &op = steps_[e].rows.h_op, &prev = steps_[e - 1].rows.h_op;
-                bool chain = op.nterms > 0;
-                for (int t = 0; t < op.nterms; ++t)
-                    chain &= op.t[t].x.base == 0 && op.t[t].x.off == gather_out(prev);
-                if (!chain) break;
-            }
-            ++e;
+        while (e < steps_.size() && steps_[e].kind == PcStep::ROWS && steps_[e].rows.nops == 1) ++e;
+        if (e == k) {
+            out.push_back(steps_[k++]);
+            continue;
         }
-        if (e - k >= 4) {
-            std::vector<RowOp> ops;
-            for (size_t q = k; q < e; ++q) {
-                ops.push_back(steps_[q].rows.h_op);
-                (void)hipFree(steps_[q].rows.d_ops);
-            }
-            PcStep s;
-            s.kind = PcStep::PROG;
-            s.rows.d_ops = dev_upload(ops.data(), ops.size());
-            s.nphases = (int)ops.size();
-            {
-                // compact records: Chebyshev steps that only continue the previous phase's
-                // solve are marked STEP (kernels.hpp, PhaseLite)
-                std::vector<PhaseLite> lite(ops.size());
-                const char *ps = S_.opt("prog_steps");
-                const bool use_steps = !(ps && ps[0] == '0');
-                auto same = [](const VRef &a, const VRef &b) {
-                    return a.base == b.base && (a.base < 0 || a.off == b.off);
-                };
-                for (size_t e2 = 0; e2 < ops.size(); ++e2) {
-                    const RowOp &op = ops[e2];
-                    PhaseLite L{};
-                    L.kind = 0;
-                    if (use_steps && e2 >= 1) {
-                        const RowOp &pv = ops[e2 - 1];
-                        const bool has_pkm1 = op.pkm1.base >= 0;
-                        bool stepk = op.mode == EPI_CHEB && pv.mode == EPI_CHEB &&
-                                     op.nterms == 1 && pv.nterms == 1 &&
-                                     op.t[0].vals == pv.t[0].vals && op.col == pv.col &&
-                                     op.rowmask == pv.rowmask && op.dinv == pv.dinv &&
-                                     op.nslices == pv.nslices && op.nrows == pv.nrows &&
-                                     same(op.b, pv.b) && op.b.base == 0 && op.y.base == 0 &&
-                                     op.pk.base == 0 && same(op.pk, pv.y) &&
-                                     same(op.t[0].x, pv.y) &&
-                                     (!has_pkm1 || (pv.pk.base == 0 && same(op.pkm1, pv.pk)));
-                        if (stepk) {
-                            L.kind = 1;
-                            L.flags = has_pkm1 ? 1u : 0u;
-                            L.y = (uint64_t)op.y.off;
-                            L.c1 = op.c1;
-                            L.c2 = op.c2;
-                            L.c3 = op.c3;
-                            L.post1 = op.post1;
-                            L.post2 = op.post2;
-                        }
-                    }
-                    lite[e2] = L;
-                }
-                s.d_lite = dev_upload(lite.data(), lite.size());
-            }
-            s.granule = prog_granule_;
-            s.gmode = prog_mode_;
-            out.push_back(s);
+        if (e - k >= 4 && use_tiles && fuse_tile_run(k, e, out)) {
             k = e;
-        } else {
-            const size_t stop = std::max(e, k + 1);
-            for (size_t q = k; q < stop; ++q) out.push_back(steps_[q]);
-            k = stop;
+            continue;
         }
+        // row programs; the data-flow form needs phase ph >= 1 to gather exactly what phase
+        // ph - 1 produced, so a run is cut where that chain breaks
+        size_t q = k;
+        while (q < e) {
+            size_t q1 = q + 1;
+            while (q1 < e) {
+                if (prog_granule_ && legacy_ok_) {
+                    const RowOp &op = steps_[q1].rows.h_op, &prev = steps_[q1 - 1].rows.h_op;
+                    bool chain = op.nterms > 0;
+                    for (int t = 0; t < op.nterms; ++t)
+                        chain &= op.t[t].x.base == 0 && op.t[t].x.off == gather_out(prev);
+                    if (!chain) break;
+                }
+                ++q1;
+            }
+            if (q1 - q >= 4 && legacy_ok_)
+                emit_prog(q, q1);
+            else
+                for (size_t i = q; i < q1; ++i) out.push_back(steps_[i]);
+            q = q1;
+        }
+        k = e;
     }
     steps_.swap(out);
 }
@@ -351,7 +481,7 @@ void SchurPC::time_programs(float *ms, int *launches, int64_t *phases) {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
     size_t k = 0;
     while (k < steps_.size()) {
-        if (steps_[k].kind == PcStep::PROG) {
+        if (steps_[k].kind == PcStep::PROG || steps_[k].kind == PcStep::TILE) {
             hipEvent_t a, b;
             HIPCHK(hipEventCreate(&a));
             HIPCHK(hipEventCreate(&b));
@@ -382,8 +512,18 @@ void SchurPC::check() {
     HIPCHK(hipMemcpyAsync(&e, d_err_, sizeof e, hipMemcpyDeviceToHost, S_.stream));
     HIPCHK(hipStreamSynchronize(S_.stream));
     if (e) {
-        HIPCHK(hipMemset(d_err_, 0, sizeof(unsigned)));
-        fail(KKT_ERR_HIP, "persistent sweep kernel timed out waiting for a neighbour workgroup");
+        unsigned rec[24] = {0};
+        HIPCHK(hipMemcpy(rec, d_err_, sizeof rec, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemset(d_err_, 0, sizeof rec));
+        std::string msg = "persistent sweep kernel timed out waiting for a neighbour workgroup";
+        if (e & 4u)
+            msg += " (tile form: tile " + std::to_string(rec[8]) + ", hand-off " +
+                   std::to_string(rec[9]) + ", local row " + std::to_string(rec[10]) +
+                   ", global row " + std::to_string(rec[11]) + ", tags seen new " +
+                   std::to_string(rec[12]) + "/" + std::to_string(rec[13]) + " old " +
+                   std::to_string(rec[14]) + "/" + std::to_string(rec[15]) +
+                   (rec[16] ? ", both iterates)" : ", newest iterate only)");
+        fail(KKT_ERR_HIP, msg);
     }
 }
 
@@ -584,13 +724,52 @@ void SchurPC::emit_update_and_solve(Lin upd, const Solve &sv, int its, double em
     upd.y2 = its == 1 ? sv.out : P_[0];
     upd.dinv = sv.dinv;
     upd.c3 = 2.0 / (emax + emin);
+    SweepLevel lv;
+    lv.first = steps_.size();
     emit_lin({upd});
-    emit_solves({sv}, its, emin, emax, P_, nx_, true);
+    emit_solves({sv}, its, emin, emax, P_, nx_, true, &lv.coef);
+    lv.last = steps_.size();
+    lv.its = its;
+    // what the tile form can express: b = ca * sum_t U_t x + cy * b_in with one x
+    bool ok = its >= 2 && !upd.terms.empty() && upd.terms.size() <= 2 && upd.cz == 0.0 && !upd.z &&
+              upd.yin != nullptr;
+    for (const Term &t : upd.terms) ok = ok && t.x == upd.terms[0].x;
+    if (ok) {
+        TileLevel &L = lv.lev;
+        L.vals = sv.vals;
+        L.dinv = sv.dinv;
+        L.bin = upd.yin;
+        // The plain steps update the right-hand side in place.  A tile re-computes the rows of
+        // its rings from b_in, so an in-place store by the owner would race with its neighbours'
+        // reads: the updated right-hand side stays on chip (nothing reads B_i after a sweep: the
+        // next batched step overwrites it).
+        L.bout = upd.y == upd.yin ? nullptr : upd.y;
+        L.out = sv.out;
+        L.x_prev = upd.terms[0].x;
+        L.n_upd = (int32_t)upd.terms.size();
+        for (size_t t = 0; t < upd.terms.size(); ++t) L.upd_vals[t] = upd.terms[t].vals;
+        L.ca = upd.ca;
+        L.cy = upd.cy;
+        L.p1_scale = upd.c3;
+        L.post1 = sv.post1;
+        L.post2 = sv.post2;
+        lv.eligible = true;
+    }
+    sweep_levels_.push_back(lv);
 }
 
 void SchurPC::emit_solves(const std::vector<Solve> &sv, int its, double emin, double emax,
-                          double *const P[3], int64_t pstride, bool first_done) {
+                          double *const P[3], int64_t pstride, bool first_done,
+                          std::vector<TileCoef> *coef_out) {
     const size_t m = sv.size();
+    // a single solve on a final right-hand side is a sweep level without update (the first
+    // level of a sweep, the sub-solves of the stationary preconditioner)
+    SweepLevel solo;
+    const bool record_solo = m == 1 && !first_done && its >= 2;
+    if (record_solo) {
+        solo.first = steps_.size();
+        coef_out = &solo.coef;
+    }
     std::vector<Cheb> ops(m);
     if (its == 0) {
         for (size_t q = 0; q < m; ++q)
@@ -627,9 +806,26 @@ void SchurPC::emit_solves(const std::vector<Solve> &sv, int its, double emin, do
                           1.0 - omega, omega, scale * omega,
                           last ? sv[q].post1 : 1.0, last ? sv[q].post2 : 1.0};
         }
+        if (coef_out) coef_out->push_back(TileCoef{1.0 - omega, omega, scale * omega});
         emit_cheb(ops);
         c_km1 = c_k;
         c_k = c_kp1;
+    }
+    if (record_solo) {
+        solo.last = steps_.size();
+        solo.its = its;
+        TileLevel &L = solo.lev;
+        L.vals = sv[0].vals;
+        L.dinv = sv[0].dinv;
+        L.bin = sv[0].b;
+        L.bout = nullptr;
+        L.out = sv[0].out;
+        L.n_upd = 0;
+        L.p1_scale = scale;
+        L.post1 = sv[0].post1;
+        L.post2 = sv[0].post2;
+        solo.eligible = true;
+        sweep_levels_.push_back(solo);
     }
 }
 
@@ -912,6 +1108,31 @@ void SchurPC::replay(size_t first, size_t last) {
                 else
                     launch_row_program(st, s.rows.d_ops, s.nphases, prog_nwg_, prog_wpw_, P.R,
                                        P.uniform_w, d_dep_, d_flags_, d_err_);
+                break;
+            }
+            case PcStep::TILE: {
+                const TilePlan &tp = tile_plan_;
+                TileArgs a{};
+                a.nlevels = s.nlevels;
+                a.its = s.its;
+                a.depth = tp.depth;
+                a.nk_pad = tp.nk_pad;
+                a.rpt = tp.rpt;
+                a.W = tp.W;
+                a.gnew[0] = d_tg_[0];
+                a.gnew[1] = d_tg_[1];
+                a.gold[0] = d_tg_[2];
+                a.gold[1] = d_tg_[3];
+                const size_t words = 2 * (size_t)S_.patterns[m_pat_].nrows;
+                a.granule_bytes = (unsigned)(words * sizeof(unsigned long long));
+                a.err = d_err_;
+                a.stamps = S_.opt("stamps") != nullptr;
+                {
+                    const char *pd = S_.opt("tile_poll_delay");
+                    a.poll_delay = pd ? std::atoi(pd) : 0;
+                }
+                launch_tile_sweep(st, a, s.d_levels, tp.d_n, tp.d_grow, tp.d_lcol, tp.d_gpos, mask_,
+                                  tp.ntiles, tp.threads, words);
                 break;
             }
             case PcStep::COMM:

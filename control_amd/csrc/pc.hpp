@@ -7,11 +7,12 @@
 
 #include "comm.hpp"
 #include "system.hpp"
+#include "tiles.hpp"
 
 namespace kkt {
 
 struct PcStep {
-    enum Kind { ROWS, TIME, COPY, COMM, PROG, EV_RECORD, EV_WAIT } kind;
+    enum Kind { ROWS, TIME, COPY, COMM, PROG, TILE, EV_RECORD, EV_WAIT } kind;
     int lane = 0;                   // 0: the system's stream; 1: the side stream
     int ev = -1;                    // EV_RECORD / EV_WAIT: event index
     RowLaunch rows;                 // ROWS
@@ -25,6 +26,8 @@ struct PcStep {
     bool granule = false;           // PROG: data-flow form (tagged granules)
     PhaseLite *d_lite = nullptr;    // PROG: compact per-phase records (data-flow form)
     int gmode = 0;                  // PROG: 0 counters, 1 data-flow fixed width, 2 data-flow any width
+    TileLevel *d_levels = nullptr;  // TILE: nlevels time levels of `its` steps each
+    int nlevels = 0, its = 0;
 };
 
 // A device-resident pc_fn: reads the nullspace-corrected right-hand side from in(), leaves
@@ -114,6 +117,23 @@ class SchurPC : public PcBase {
     unsigned long long *d_g0_ = nullptr, *d_g1_ = nullptr;
     size_t granule_words_ = 0;
     void fuse_programs();
+    bool setup_row_programs();
+    bool legacy_tried_ = false, legacy_ok_ = false;
+    // tile form (tile_kernels.hip): levels of the sweeps as the emit functions recorded them
+    struct SweepLevel {
+        size_t first = 0, last = 0;     // steps_[first, last) are the level's single-block steps
+        TileLevel lev{};
+        std::vector<TileCoef> coef;     // steps 2 .. its
+        int its = 0;
+        bool eligible = false;
+    };
+    std::vector<SweepLevel> sweep_levels_;
+    TilePlan tile_plan_;
+    bool tile_tried_ = false, tile_ok_ = false;
+    unsigned long long *d_tg_[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<void *> tile_owned_;    // coefficient tables of the current program
+    bool prepare_tiles();
+    bool fuse_tile_run(size_t k, size_t e, std::vector<PcStep> &out);
 
     struct Term {
         const double *vals;
@@ -151,7 +171,8 @@ class SchurPC : public PcBase {
         double post1 = 1.0, post2 = 1.0;
     };
     void emit_solves(const std::vector<Solve> &sv, int its, double emin, double emax,
-                     double *const P[3], int64_t pstride, bool first_done = false);
+                     double *const P[3], int64_t pstride, bool first_done = false,
+                     std::vector<TileCoef> *coef_out = nullptr);
     // the sweep step "b -= A u_prev (masked), then solve": the update and the first
     // Chebyshev step share one launch
     void emit_update_and_solve(Lin upd, const Solve &sv, int its, double emin, double emax);

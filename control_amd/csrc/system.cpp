@@ -259,6 +259,7 @@ int System::find_or_add_pattern(int64_t nrows, int64_t ncols, const int32_t *ind
     }
     P.d_col = dev_upload(col.data(), col.size());
     P.d_slice_off = dev_upload(off.data(), off.size());
+    P.h_slice_off = off;
     P.d_sell2csr = dev_upload(map.data(), map.size());
     patterns.push_back(std::move(P));
     info.bytes_device_index += patterns.back().npadded * 4 + (patterns.back().nslices + 1) * 4 +

@@ -49,6 +49,12 @@ struct Pattern {
     std::vector<int32_t> h_indptr, h_indices;   // kept to prove equality, not just hash
     int32_t *d_col = nullptr;
     int32_t *d_slice_off = nullptr;
+    std::vector<int32_t> h_slice_off;   // nslices + 1 offsets in slots (host copy)
+    // index into a SELL value array of entry k (CSR order) of row r
+    int64_t sell_index(int64_t r, int k) const {
+        const int64_t C = 64 * R, pos = pos_of(r), s = pos / C, rin = pos - s * C;
+        return ((int64_t)h_slice_off[s] + k) * C + (rin % 64) * R + rin / 64;
+    }
     int32_t *d_sell2csr = nullptr;
     // row-sorted storage (SELL-C-sigma): row held by each position / position of each row;
     // empty and null when position == row
@@ -178,6 +184,7 @@ struct System {
     std::unique_ptr<Comm> comm;
 
     KrylovCfg ksp;
+    kkt_steplock steplock{};   // test hook (kkt_debug_set_steplock); n_steps == 0: off
     // execution options (kkt_set_option); a key that was never set falls back to the
     // environment variable KKT_<KEY> (developer scripts), then to the built-in default
     std::map<std::string, std::string> options;

@@ -1,0 +1,457 @@
+// Tile sweep program for gfx950: the serial time sweeps of the block-Schur preconditioner
+// (reference control/control.py:2263-2295, 2375-2406) as ONE persistent launch in which a
+// workgroup advances `depth` dependent SpMV steps per hand-off (matrix-powers kernel; plan and
+// rationale: tiles.hpp).
+//
+// One workgroup per CU owns one tile: its own rows plus the rings within graph distance
+// `depth`.  State per workgroup:
+//   registers  matrix values and local column indices of the rows it ever computes
+//              (rows [0, n[depth-1]) of the tile, RPT per thread), Jacobi diagonal, right-hand side
+//   LDS        the two newest iterates on all n[depth] local rows
+// A step computes p_s on the rows whose columns are still valid (one ring fewer than the step
+// before) out of LDS; when the rings are used up, the own rows of the two newest iterates are
+// published as tagged granules and the rings are re-gathered from the owners' granules
+// ("the data is the flag", cdna_hip_programming.md Guideline 16 R2: no flag, no drain, no
+// grid barrier).  Granule buffers alternate with the hand-off epoch; write-after-read safety
+// is the argument of pc_row_program_g at tile granularity (a tile publishes epoch e + 1 only
+// after it has seen epoch e of every tile it gathers from, and those tiles gather from it).
+//
+// Arithmetic: every row keeps the fma chain of the plain kernels (kernels.hip rowops_body:
+// CSR order inside a term, terms in order) and the same epilogue expressions, so the results
+// equal the plain launches bit for bit (tests/test_gpu_parity.py).
+#include "kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+namespace kkt {
+
+#define KKT_GLOBAL __attribute__((address_space(1)))
+typedef KKT_GLOBAL const double *gcd_p;
+typedef KKT_GLOBAL double *gd_p;
+typedef KKT_GLOBAL const int32_t *gci_p;
+typedef KKT_GLOBAL const uint16_t *gcu16_p;
+typedef KKT_GLOBAL const uint8_t *gcb_p;
+typedef KKT_GLOBAL unsigned long long *gu64_p;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned TILE_SPIN_LIMIT = 1u << 21;
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter (s_waitcnt vmcnt(0)): every outstanding global load or write-through store would cost
+// a round trip per local step.  Global data is ordered by the granule tags, not by barriers.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// one row's value as a 16-byte granule {lo, tag, hi, tag}: ONE write-through (sc1) store
+__device__ __forceinline__ void publish(const __amdgpu_buffer_rsrc_t rs, int grow, double v,
+                                        unsigned tag) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    const u32x4 g = {(unsigned)bits, tag, (unsigned)(bits >> 32), tag};
+    __builtin_amdgcn_raw_buffer_store_b128(g, rs, grow * 16, 0, 16 /* sc1 */);
+}
+
+template <int W, int RPT, int TMAX>
+__global__ __launch_bounds__(TMAX) void pc_tile_sweep(
+    const TileArgs A, const TileLevel *__restrict__ levels, const int32_t *__restrict__ n_all,
+    const int32_t *__restrict__ grow_all, const uint16_t *__restrict__ lcol_all,
+    const int32_t *__restrict__ gpos_all, const uint8_t *__restrict__ rowmask_) {
+    constexpr int HPT = RPT + 1;
+    extern __shared__ double X[];
+    __shared__ int sn[TILE_DEPTH_MAX + 1];
+    __shared__ int sdead;
+    const int T = blockDim.x, tid = threadIdx.x, tile = blockIdx.x;
+    const int nkp = A.nk_pad, depth = A.depth, its = A.its;
+    const int32_t *nt = n_all + (size_t)tile * (TILE_DEPTH_MAX + 1);
+    const int n0 = nt[0], nk = nt[depth], nk1 = nt[depth - 1];
+    if (tid <= TILE_DEPTH_MAX) sn[tid] = nt[tid];
+    if (tid == 0) sdead = 0;
+    const gci_p grow = (gci_p)grow_all + (size_t)tile * nkp;
+    const gcb_p rowmask = (gcb_p)rowmask_;
+
+    // ---- what never changes during the launch: structure of the rows this thread computes.
+    // Narrow rows (2-D P1): local column indices and the positions of the matrix values in a
+    // SELL array stay in registers.  Wide rows (3-D P1, P2): columns are packed two to a
+    // register and the positions are re-read from memory once per level and matrix.
+    constexpr bool PACK = W > 9;
+    constexpr int WP = (W + 1) / 2;
+    constexpr int CW = PACK ? WP : W, GW = PACK ? 1 : W;
+    unsigned cpk[RPT][CW];
+    int gpr[RPT][GW];
+    int gr[RPT];
+    bool msk[RPT];
+    const gcu16_p lcol = (gcu16_p)lcol_all + (size_t)tile * RPT * W * T + tid;
+    const gci_p gpos = (gci_p)gpos_all + (size_t)tile * RPT * W * T + tid;
+#pragma unroll
+    for (int sl = 0; sl < RPT; ++sl) {
+        const int r = sl * T + tid;
+        if constexpr (PACK) {
+#pragma unroll
+            for (int k = 0; k < W; k += 2) {
+                const unsigned lo = lcol[(size_t)(sl * W + k) * T];
+                const unsigned hi = k + 1 < W ? lcol[(size_t)(sl * W + k + 1) * T] : 0u;
+                cpk[sl][k / 2] = lo | (hi << 16);
+            }
+            gpr[sl][0] = 0;
+        } else {
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                cpk[sl][k] = lcol[(size_t)(sl * W + k) * T];
+                gpr[sl][k] = gpos[(size_t)(sl * W + k) * T];
+            }
+        }
+        gr[sl] = r < nk1 ? grow[r] : -1;
+        msk[sl] = gr[sl] >= 0 && rowmask != nullptr && rowmask[gr[sl]] != 0;
+    }
+#define KKT_COL(sl, k)                                                                       \
+    (int)(PACK ? (((k) & 1) ? (cpk[sl][PACK ? (k) / 2 : 0] >> 16) : (cpk[sl][PACK ? (k) / 2 : 0] & 0xffffu)) \
+               : cpk[sl][PACK ? 0 : (k)])
+#define KKT_GP(sl, k) (PACK ? gpos[(size_t)((sl) * W + (k)) * T] : gpr[sl][PACK ? 0 : (k)])
+    // ... and the ring entries it gathers at a hand-off
+    int hl[HPT], hg[HPT];
+#pragma unroll
+    for (int h = 0; h < HPT; ++h) {
+        const int l = n0 + h * T + tid;
+        hl[h] = l < nk ? l : -1;
+        hg[h] = l < nk ? grow[l] : 0;
+    }
+
+    // step coefficients live in LDS behind the two iterates: a global load inside the step loop
+    // would be drained by every workgroup barrier (vmcnt(0)), a round trip per step
+    double *scoef = X + 2 * (size_t)nkp;
+    const void *coef_key = nullptr;
+    int cur = 0;             // X + cur * nkp: the newest iterate; the other half: the one before
+    unsigned epoch = 0;
+    bool dead = false;       // a spin timed out: stop waiting, run to the end, results invalid
+    const void *vals_key = nullptr;
+    double v[RPT][W];
+
+    // diagnostics (option "stamps"): 100 MHz ticks this workgroup spent in hand-offs / local
+    // steps / level prologues, counts, poll rounds -- 8 x 64-bit words per tile at err + 64
+    unsigned long long *stat = reinterpret_cast<unsigned long long *>(A.err + 64) + (size_t)tile * 8;
+    const bool stamps = A.stamps != 0;
+    unsigned long long t_mark = stamps ? wall_clock64() : 0ull;
+    auto lap = [&](int slot, unsigned long long count) {
+        if (!stamps) return;
+        const unsigned long long now = wall_clock64();
+        if (tid == 0) {
+            stat[slot] += now - t_mark;
+            stat[slot + 3] += count;
+        }
+        t_mark = now;
+    };
+
+    // publish the own rows of the newest (and the previous) iterate, re-gather the rings
+    auto handoff = [&](const bool both) {
+        lap(1, 0);
+        ++epoch;
+        double *Xc = X + cur * nkp, *Xo = X + (cur ^ 1) * nkp;
+        const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)A.gnew[epoch & 1], 0, (int)A.granule_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)A.gold[epoch & 1], 0, (int)A.granule_bytes, 0x00020000);
+#pragma unroll
+        for (int sl = 0; sl < RPT; ++sl) {
+            const int r = sl * T + tid;
+            if (r < n0) {
+                publish(rn, gr[sl], Xc[r], epoch);
+                if (both) publish(ro, gr[sl], Xo[r], epoch);
+            }
+        }
+        const gu64_p gn = (gu64_p)A.gnew[epoch & 1], go = (gu64_p)A.gold[epoch & 1];
+        unsigned long long na[HPT], nb[HPT], oa[HPT], ob[HPT];
+        bool want_o[HPT];
+#pragma unroll
+        for (int h = 0; h < HPT; ++h) {
+            want_o[h] = both && hl[h] >= 0 && hl[h] < nk1;
+            na[h] = nb[h] = oa[h] = ob[h] = (unsigned long long)epoch << 32;
+        }
+        // a poll samples memory about half a round trip after it is issued; the neighbours'
+        // granules, stored at about the same time as this tile's, take about one: polling at
+        // once mostly fails and costs a second round trip
+        for (int i = 0; i < A.poll_delay; ++i) __builtin_amdgcn_s_sleep(1);
+        unsigned spins = 0;
+        while (true) {
+            bool ok = true;
+#pragma unroll
+            for (int h = 0; h < HPT; ++h) {
+                if (hl[h] >= 0) {
+                    const gu64_p g = gn + 2 * (size_t)hg[h];
+                    na[h] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    nb[h] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (want_o[h]) {
+                    const gu64_p g = go + 2 * (size_t)hg[h];
+                    oa[h] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ob[h] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < HPT; ++h)
+                ok &= (unsigned)(na[h] >> 32) == epoch && (unsigned)(nb[h] >> 32) == epoch &&
+                      (unsigned)(oa[h] >> 32) == epoch && (unsigned)(ob[h] >> 32) == epoch;
+            if (ok || dead) break;
+            if (++spins >= TILE_SPIN_LIMIT) {
+                // record who waited for what: tile, epoch, local index, global row, tags seen
+                dead = true;
+                sdead = 1;
+                atomicOr(A.err, 4u);
+                if (atomicCAS(A.err + 1, 0u, 1u) == 0u) {
+#pragma unroll
+                    for (int h = 0; h < HPT; ++h)
+                        if (hl[h] >= 0 && ((unsigned)(na[h] >> 32) != epoch ||
+                                           (unsigned)(nb[h] >> 32) != epoch ||
+                                           (unsigned)(oa[h] >> 32) != epoch ||
+                                           (unsigned)(ob[h] >> 32) != epoch)) {
+                            A.err[8] = (unsigned)tile;
+                            A.err[9] = epoch;
+                            A.err[10] = (unsigned)hl[h];
+                            A.err[11] = (unsigned)hg[h];
+                            A.err[12] = (unsigned)(na[h] >> 32);
+                            A.err[13] = (unsigned)(nb[h] >> 32);
+                            A.err[14] = (unsigned)(oa[h] >> 32);
+                            A.err[15] = (unsigned)(ob[h] >> 32);
+                            A.err[16] = both ? 1u : 0u;
+                        }
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int h = 0; h < HPT; ++h) {
+            if (hl[h] >= 0)
+                Xc[hl[h]] = __longlong_as_double(
+                    (long long)((na[h] & 0xffffffffull) | (nb[h] << 32)));
+            if (want_o[h])
+                Xo[hl[h]] = __longlong_as_double(
+                    (long long)((oa[h] & 0xffffffffull) | (ob[h] << 32)));
+        }
+        // a wave that leaves this barrier knows every wave of the workgroup has finished reading
+        // the granules of this epoch; only then may anyone publish the next one
+        lds_barrier();
+        dead = sdead != 0;
+        if (stamps && tid == 0) stat[6] += spins;
+        lap(0, 1);
+    };
+
+    for (int lev = 0; lev < A.nlevels; ++lev) {
+        const TileLevel &L = levels[lev];
+        // ---- operands of the level: matrix values (re-loaded only when the pointer changes,
+        // i.e. per level in mode G, once in mode S), diagonal, right-hand side
+        if ((const void *)L.vals != vals_key) {
+            vals_key = (const void *)L.vals;
+            const gcd_p vp = (gcd_p)L.vals;
+#pragma unroll
+            for (int sl = 0; sl < RPT; ++sl) {
+                int gp[W];
+#pragma unroll
+                for (int k = 0; k < W; ++k) gp[k] = KKT_GP(sl, k);
+#pragma unroll
+                for (int k = 0; k < W; ++k) v[sl][k] = gp[k] >= 0 ? vp[gp[k]] : 0.0;
+            }
+        }
+        if ((const void *)L.coef != coef_key) {
+            coef_key = (const void *)L.coef;
+            const gcd_p cp = (gcd_p)(const double *)L.coef;
+            __syncthreads();   // nobody still reads the old table
+            for (int i = tid; i < 3 * (its - 1); i += T) scoef[i] = cp[i];
+            // (the barrier after the first step of the level orders these writes before their use)
+        }
+        const double post1 = L.post1, post2 = L.post2;
+        double dinv[RPT], b[RPT];
+        {
+            const gcd_p dp = (gcd_p)L.dinv, bp = (gcd_p)L.bin;
+#pragma unroll
+            for (int sl = 0; sl < RPT; ++sl) {
+                dinv[sl] = gr[sl] >= 0 ? dp[gr[sl]] : 0.0;
+                b[sl] = gr[sl] >= 0 ? bp[gr[sl]] : 0.0;
+            }
+        }
+        int cr;
+        {
+            double *Xc = X + cur * nkp, *Xo = X + (cur ^ 1) * nkp;
+            if (L.n_upd > 0) {
+                if (!L.prev_in_lds) {
+                    // produced before this launch (or by another rank): plain memory
+                    const gcd_p xp = (gcd_p)L.x_prev;
+                    for (int l = tid; l < nk; l += T) Xc[l] = xp[grow[l]];
+                    lds_barrier();
+                }
+                // b = ca * (sum_t U_t x_prev) + cy * b_in, 0 on boundary rows; p_1 = scale D^-1 b
+                double acc[RPT];
+#pragma unroll
+                for (int sl = 0; sl < RPT; ++sl) acc[sl] = 0.0;
+                for (int t = 0; t < L.n_upd; ++t) {
+                    const gcd_p up = (gcd_p)L.upd_vals[t];
+#pragma unroll
+                    for (int sl = 0; sl < RPT; ++sl) {
+                        if (sl * T >= nk1) continue;
+                        int gp[W];
+                        double vu[W];
+#pragma unroll
+                        for (int k = 0; k < W; ++k) gp[k] = KKT_GP(sl, k);
+#pragma unroll
+                        for (int k = 0; k < W; ++k)
+                            vu[k] = (gr[sl] >= 0 && gp[k] >= 0) ? up[gp[k]] : 0.0;
+#pragma unroll
+                        for (int k = 0; k < W; ++k)
+                            acc[sl] = __builtin_fma(vu[k], Xc[KKT_COL(sl, k)], acc[sl]);
+                    }
+                }
+                const gd_p bo = (gd_p)L.bout;
+#pragma unroll
+                for (int sl = 0; sl < RPT; ++sl) {
+                    const int r = sl * T + tid;
+                    double out;
+                    if (msk[sl]) {
+                        out = 0.0;
+                    } else {
+                        double t = L.ca * acc[sl];
+                        t += L.cy * b[sl];
+                        out = t;
+                    }
+                    const double out2 = L.p1_scale * (dinv[sl] * out);
+                    b[sl] = out;
+                    if (r < nk1) Xo[r] = out2;
+                    if (r < n0 && bo != nullptr) bo[gr[sl]] = out;
+                }
+            } else {
+                // first step of a solve on a right-hand side that is already final
+                const bool last = its == 1;
+                const double q1 = last ? post1 : 1.0, q2 = last ? post2 : 1.0;
+#pragma unroll
+                for (int sl = 0; sl < RPT; ++sl) {
+                    const int r = sl * T + tid;
+                    double out = 0.0;
+                    if (!msk[sl]) {
+                        double t = 0.0;
+                        t += L.p1_scale * (dinv[sl] * (b[sl] - 0.0));
+                        out = q2 * (q1 * t);
+                    }
+                    if (r < nk1) Xo[r] = out;
+                }
+            }
+            cr = depth - 1;
+            lds_barrier();
+            cur ^= 1;
+        }
+        lap(2, 1);
+        // ---- Chebyshev steps 2 .. its, `depth` of them per hand-off
+        for (int s = 2; s <= its; ++s) {
+            if (cr == 0) {
+                handoff(s >= 3);
+                cr = depth;
+            }
+            const int nv = sn[cr - 1];
+            const double cf1 = scoef[3 * (s - 2)], cf2 = scoef[3 * (s - 2) + 1],
+                         cf3 = scoef[3 * (s - 2) + 2];
+            const bool last = s == its;
+            const double q1 = last ? post1 : 1.0, q2 = last ? post2 : 1.0;
+            const bool has_old = s >= 3;
+            double *Xc = X + cur * nkp, *Xo = X + (cur ^ 1) * nkp;
+#pragma unroll
+            for (int sl = 0; sl < RPT; ++sl) {
+                if (sl * T >= nv) continue;          // wave-uniform: nothing of this slot is live
+                const int r = sl * T + tid;
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < W; ++k) acc = __builtin_fma(v[sl][k], Xc[KKT_COL(sl, k)], acc);
+                if (r < nv) {
+                    const double e0 = Xo[r], e1 = Xc[r];
+                    double out = 0.0;
+                    if (!msk[sl]) {
+                        double t = has_old ? cf1 * e0 : 0.0;
+                        t += cf2 * e1;
+                        t += cf3 * (dinv[sl] * (b[sl] - acc));
+                        out = q2 * (q1 * t);
+                    }
+                    Xo[r] = out;
+                }
+            }
+            lds_barrier();
+            cur ^= 1;
+            --cr;
+        }
+        lap(1, (unsigned long long)(its - 1));
+        // ---- result of the level: own rows to memory; the next level's update multiplies it
+        {
+            double *Xc = X + cur * nkp;
+            const gd_p op = (gd_p)L.out;
+#pragma unroll
+            for (int sl = 0; sl < RPT; ++sl) {
+                const int r = sl * T + tid;
+                if (r < n0) op[gr[sl]] = Xc[r];
+            }
+            if (lev + 1 < A.nlevels) {
+                const TileLevel &N = levels[lev + 1];
+                if (N.n_upd > 0 && N.prev_in_lds) handoff(false);
+            }
+        }
+    }
+}
+
+#undef KKT_COL
+#undef KKT_GP
+
+typedef void (*tile_fn)(const TileArgs, const TileLevel *, const int32_t *, const int32_t *,
+                        const uint16_t *, const int32_t *, const uint8_t *);
+// workgroups of at most 512 threads may use 256 registers per thread; 1024-thread workgroups
+// (four row slots fewer per thread for the big tiles of 3-D meshes) 128
+static tile_fn pick_tile(int W, int rpt, int threads) {
+    const bool big = threads > 512;
+#define KKT_T(w)                                                                     \
+    if (W == w) {                                                                    \
+        switch (rpt) {                                                               \
+            case 1: return big ? pc_tile_sweep<w, 1, 1024> : pc_tile_sweep<w, 1, 512>; \
+            case 2: return big ? pc_tile_sweep<w, 2, 1024> : pc_tile_sweep<w, 2, 512>; \
+            case 3: return big ? nullptr : pc_tile_sweep<w, 3, 512>;                 \
+            default: return nullptr;                                                 \
+        }                                                                            \
+    }
+    KKT_T(5) KKT_T(7) KKT_T(9) KKT_T(15)
+#undef KKT_T
+    return nullptr;
+}
+
+size_t tile_sweep_lds_bytes(int nk_pad, int its) {
+    return (2 * (size_t)nk_pad + 3 * (size_t)std::max(1, its - 1)) * sizeof(double);
+}
+
+bool tile_sweep_available(int W, int rpt, int threads) {
+    return threads >= 64 && threads <= 1024 && threads % 64 == 0 &&
+           pick_tile(W, rpt, threads) != nullptr;
+}
+
+int tile_sweep_max_tiles(int W, int rpt, int threads, size_t lds_bytes) {
+    tile_fn f = pick_tile(W, rpt, threads);
+    int dev = 0, cus = 0, per_cu = 0;
+    if (!f || hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (lds_bytes > 48 * 1024 &&
+        hipFuncSetAttribute((const void *)f, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_bytes) != hipSuccess)
+        return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, threads, lds_bytes) != hipSuccess)
+        return 0;
+    return per_cu >= 1 ? cus : 0;   // one workgroup per CU
+}
+
+void launch_tile_sweep(hipStream_t s, const TileArgs &a, const TileLevel *d_levels,
+                       const int32_t *d_n, const int32_t *d_grow, const uint16_t *d_lcol,
+                       const int32_t *d_gpos, const uint8_t *d_rowmask, int ntiles, int threads,
+                       size_t granule_words) {
+    if (a.nlevels <= 0 || ntiles <= 0) return;
+    // tags of an earlier launch must not match this launch's epochs
+    for (int i = 0; i < 2; ++i) {
+        (void)hipMemsetAsync(a.gnew[i], 0, granule_words * sizeof(unsigned long long), s);
+        (void)hipMemsetAsync(a.gold[i], 0, granule_words * sizeof(unsigned long long), s);
+    }
+    const size_t lds = tile_sweep_lds_bytes(a.nk_pad, a.its);
+    hipLaunchKernelGGL(pick_tile(a.W, a.rpt, threads), dim3(ntiles), dim3(threads), lds, s, a, d_levels,
+                       d_n, d_grow, d_lcol, d_gpos, d_rowmask);
+}
+
+}  // namespace kkt

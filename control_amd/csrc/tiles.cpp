@@ -1,0 +1,260 @@
+// Host side of the tile sweep program: graph partition of a sparsity structure into compact
+// tiles, their rings, and the tile-local matrix layout (tiles.hpp).
+#include "tiles.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <numeric>
+#include <set>
+
+namespace kkt {
+
+namespace {
+
+struct Bisector {
+    const Pattern &P;
+    std::vector<int32_t> &part;
+    std::vector<int32_t> stamp, dist, queue;
+    int32_t cur = 0;
+
+    Bisector(const Pattern &P_, std::vector<int32_t> &part_)
+        : P(P_), part(part_), stamp(P_.nrows, 0), dist(P_.nrows, 0) {
+        queue.reserve(P_.nrows);
+    }
+
+    // BFS inside the subset stamped `cur`; unreached members get max + 1.  Returns a farthest
+    // reached node.
+    int32_t bfs(const std::vector<int32_t> &nodes, int32_t src) {
+        for (int32_t v : nodes) dist[v] = -1;
+        queue.clear();
+        queue.push_back(src);
+        dist[src] = 0;
+        int32_t far = src;
+        for (size_t h = 0; h < queue.size(); ++h) {
+            const int32_t v = queue[h];
+            far = v;
+            for (int32_t q = P.h_indptr[v]; q < P.h_indptr[v + 1]; ++q) {
+                const int32_t c = P.h_indices[q];
+                if (c < (int32_t)P.nrows && stamp[c] == cur && dist[c] < 0) {
+                    dist[c] = dist[v] + 1;
+                    queue.push_back(c);
+                }
+            }
+        }
+        const int32_t big = dist[far] + 1;
+        for (int32_t v : nodes)
+            if (dist[v] < 0) dist[v] = big;
+        return far;
+    }
+
+    void run(std::vector<int32_t> &nodes, int nparts, int base) {
+        if (nparts <= 1 || nodes.size() <= 1) {
+            for (int32_t v : nodes) part[v] = base;
+            return;
+        }
+        ++cur;
+        for (int32_t v : nodes) stamp[v] = cur;
+        const int32_t a = bfs(nodes, nodes[0]);
+        const int32_t b = bfs(nodes, a);
+        std::vector<int32_t> da(nodes.size());
+        for (size_t i = 0; i < nodes.size(); ++i) da[i] = dist[nodes[i]];
+        (void)bfs(nodes, b);
+        // order along the "axis" between the two far-apart rows: d(a, .) - d(b, .)
+        std::vector<int32_t> idx(nodes.size());
+        std::iota(idx.begin(), idx.end(), 0);
+        std::vector<int64_t> key(nodes.size());
+        for (size_t i = 0; i < nodes.size(); ++i)
+            key[i] = (int64_t)(da[i] - dist[nodes[i]]) * ((int64_t)1 << 40) +
+                     (int64_t)da[i] * ((int64_t)1 << 32) + nodes[i];
+        std::sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return key[x] < key[y]; });
+        const int nl = nparts / 2;
+        const size_t cut = (size_t)(((int64_t)nodes.size() * nl + nparts / 2) / nparts);
+        std::vector<int32_t> left(cut), right(nodes.size() - cut);
+        for (size_t i = 0; i < cut; ++i) left[i] = nodes[idx[i]];
+        for (size_t i = cut; i < nodes.size(); ++i) right[i - cut] = nodes[idx[i]];
+        std::vector<int32_t>().swap(nodes);
+        run(left, nl, base);
+        run(right, nparts - nl, base + nl);
+    }
+};
+
+}  // namespace
+
+void TilePlan::upload() {
+    release();
+    d_n = dev_upload(n.data(), n.size());
+    d_grow = dev_upload(grow.data(), grow.size());
+    d_gpos = dev_upload(gpos.data(), gpos.size());
+    d_lcol = dev_upload(lcol.data(), lcol.size());
+}
+
+void TilePlan::release() {
+    auto F = [](void *p) {
+        if (p) (void)hipFree(p);
+    };
+    F(d_n);
+    F(d_grow);
+    F(d_gpos);
+    F(d_lcol);
+    d_n = d_grow = d_gpos = nullptr;
+    d_lcol = nullptr;
+}
+
+bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int max_rpt,
+                     TilePlan &out) {
+    if (P.nrows != P.ncols || ntiles < 1 || depth > TILE_MAX_DEPTH) return false;
+    const bool auto_depth = depth <= 0;
+    if (auto_depth) depth = TILE_MAX_DEPTH;
+    if ((int64_t)ntiles > P.nrows) ntiles = (int)P.nrows;
+    const int64_t nrows = P.nrows;
+    out = TilePlan{};
+    out.ntiles = ntiles;
+    out.depth = depth;
+    out.threads = threads;
+    out.W = P.max_width;
+    if (out.W < 1) return false;
+    out.part.assign(nrows, 0);
+    {
+        Bisector B(P, out.part);
+        std::vector<int32_t> all(nrows);
+        std::iota(all.begin(), all.end(), 0);
+        B.run(all, ntiles, 0);
+    }
+    // rings: L_0 = own rows, L_{j+1} = L_j + columns of the rows of L_j
+    std::vector<std::vector<int32_t>> local(ntiles);   // global rows in local order
+    out.n.assign((size_t)ntiles * (TILE_MAX_DEPTH + 1), 0);
+    {
+        std::vector<std::vector<int32_t>> own(ntiles);
+        for (int64_t r = 0; r < nrows; ++r) own[out.part[r]].push_back((int32_t)r);
+        std::vector<int32_t> mark(nrows, -1);
+        for (int t = 0; t < ntiles; ++t) {
+            std::vector<int32_t> &L = local[t];
+            L = own[t];
+            for (int32_t r : L) mark[r] = t;
+            int32_t *nt = &out.n[(size_t)t * (TILE_MAX_DEPTH + 1)];
+            nt[0] = (int32_t)L.size();
+            size_t first = 0;
+            for (int j = 1; j <= depth; ++j) {
+                const size_t last = L.size();
+                std::vector<int32_t> ring;
+                for (size_t i = first; i < last; ++i)
+                    for (int32_t q = P.h_indptr[L[i]]; q < P.h_indptr[L[i] + 1]; ++q) {
+                        const int32_t c = P.h_indices[q];
+                        if (mark[c] != t) {
+                            mark[c] = t;
+                            ring.push_back(c);
+                        }
+                    }
+                std::sort(ring.begin(), ring.end());
+                L.insert(L.end(), ring.begin(), ring.end());
+                nt[j] = (int32_t)L.size();
+                first = last;
+            }
+            for (int j = depth + 1; j <= TILE_MAX_DEPTH; ++j) nt[j] = nt[depth];
+        }
+    }
+    if (auto_depth) {
+        // modelled microseconds per dependent step: one hand-off per `d` steps plus the local
+        // steps, whose cost grows with the rows per thread of the largest tile
+        double best = 1e300;
+        int best_d = 0;
+        for (int d = 1; d <= TILE_MAX_DEPTH; ++d) {
+            int64_t mk = 0, mr = 0, mh = 0;
+            for (int t = 0; t < ntiles; ++t) {
+                const int32_t *nt = &out.n[(size_t)t * (TILE_MAX_DEPTH + 1)];
+                mk = std::max<int64_t>(mk, nt[d]);
+                mr = std::max<int64_t>(mr, nt[d - 1]);
+                mh = std::max<int64_t>(mh, nt[d] - nt[0]);
+            }
+            int rp = (int)((mr + threads - 1) / threads);
+            while ((int64_t)(rp + 1) * threads < mh) ++rp;
+            if (mk > 65535 || rp > max_rpt) break;
+            const double handoff = 2.5 + 0.5 * (double)mh / threads;
+            const double step = 0.10 + 0.10 * (double)mr / threads;
+            const double per = (handoff + d * step) / d;
+            if (per < best) {
+                best = per;
+                best_d = d;
+            }
+        }
+        if (best_d == 0) return false;
+        depth = best_d;
+        out.depth = depth;
+        for (int t = 0; t < ntiles; ++t) {
+            int32_t *nt = &out.n[(size_t)t * (TILE_MAX_DEPTH + 1)];
+            for (int j = depth + 1; j <= TILE_MAX_DEPTH; ++j) nt[j] = nt[depth];
+            local[t].resize(nt[depth]);
+        }
+    }
+    int64_t max_nk = 0, max_rows = 0, max_halo = 0, max_own = 0;
+    double red = 0.0;
+    for (int t = 0; t < ntiles; ++t) {
+        const int32_t *nt = &out.n[(size_t)t * (TILE_MAX_DEPTH + 1)];
+        max_nk = std::max<int64_t>(max_nk, nt[depth]);
+        max_rows = std::max<int64_t>(max_rows, nt[depth - 1]);
+        max_halo = std::max<int64_t>(max_halo, nt[depth] - nt[0]);
+        max_own = std::max<int64_t>(max_own, nt[0]);
+        red += nt[0] ? (double)nt[depth - 1] / nt[0] : 0.0;
+    }
+    out.max_own = max_own;
+    out.max_rows = max_rows;
+    out.max_halo = max_halo;
+    out.mean_redundancy = red / ntiles;
+    if (max_nk > 65535) return false;
+    int rpt = (int)((max_rows + threads - 1) / threads);
+    while ((int64_t)(rpt + 1) * threads < max_halo) ++rpt;
+    if (rpt < 1) rpt = 1;
+    if (rpt > max_rpt) return false;
+    out.rpt = rpt;
+    out.nk_pad = (int)((max_nk + 63) & ~(int64_t)63);
+    const int W = out.W, T = threads;
+    out.grow.assign((size_t)ntiles * out.nk_pad, -1);
+    out.lcol.assign((size_t)ntiles * rpt * W * T, 0);
+    out.gpos.assign((size_t)ntiles * rpt * W * T, -1);
+    std::vector<int32_t> lidx(nrows, -1);
+    for (int t = 0; t < ntiles; ++t) {
+        const std::vector<int32_t> &L = local[t];
+        const int32_t *nt = &out.n[(size_t)t * (TILE_MAX_DEPTH + 1)];
+        for (size_t l = 0; l < L.size(); ++l) {
+            lidx[L[l]] = (int32_t)l;
+            out.grow[(size_t)t * out.nk_pad + l] = L[l];
+        }
+        const size_t base = (size_t)t * rpt * W * T;
+        for (int r = 0; r < rpt * T; ++r) {
+            const int slot = r / T, tid = r % T;
+            const bool live = r < nt[depth - 1];
+            const int32_t g = live ? L[r] : -1;
+            const int len = live ? P.h_indptr[g + 1] - P.h_indptr[g] : 0;
+            for (int k = 0; k < W; ++k) {
+                const size_t at = base + ((size_t)slot * W + k) * T + tid;
+                if (k < len) {
+                    const int32_t c = P.h_indices[P.h_indptr[g] + k];
+                    // (timing experiment only, results wrong: every gather hits the own row)
+                    static const bool nogather = std::getenv("KKT_TILE_NOGATHER") != nullptr;
+                    out.lcol[at] = (uint16_t)(nogather ? r : lidx[c]);
+                    out.gpos[at] = (int32_t)P.sell_index(g, k);
+                } else {
+                    out.lcol[at] = (uint16_t)(live ? r : 0);   // value 0: any valid index
+                    out.gpos[at] = -1;
+                }
+            }
+        }
+        for (int32_t g : L) lidx[g] = -1;
+    }
+    // the write-after-read argument of the granule buffers needs a symmetric "gathers from"
+    // relation between tiles
+    {
+        std::vector<std::set<int32_t>> reads(ntiles);
+        for (int t = 0; t < ntiles; ++t) {
+            const int32_t *nt = &out.n[(size_t)t * (TILE_MAX_DEPTH + 1)];
+            for (int l = nt[0]; l < nt[depth]; ++l) reads[t].insert(out.part[local[t][l]]);
+        }
+        out.symmetric = true;
+        for (int t = 0; t < ntiles && out.symmetric; ++t)
+            for (int32_t u : reads[t])
+                if (!reads[u].count(t)) out.symmetric = false;
+    }
+    return true;
+}
+
+}  // namespace kkt

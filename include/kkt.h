@@ -77,12 +77,13 @@ const char *kkt_last_error(kkt_handle h);
  *   "sell_sort"   "0" | "1"      row-sorted storage for ragged structures (default 1)
  *   "no_graph"    "1"            replay the preconditioner as plain launches, no hipGraph
  *   "persistent"  "0"            time sweeps as one launch per step (no sweep programs)
- *   "prog_mode"   "tile" | "flow" | "flags" | "w"   sweep-program form (default: the fastest
- *                                that fits: tile, else flow, else flags)
- *   "prog_waves"  "1".."8"       waves per workgroup of the flow / flags forms
- *   "prog_steps"  "0"            flow form without compact STEP records
- *   "tile_depth"  "1".."16"      Chebyshev steps per hand-off of the tile form
- *   "tile_waves"  "4" | "8" | "16"   waves per workgroup of the tile form
+ *   "prog_mode"   "auto" | "tile" | "dataflow" | "flags" | "w"   sweep-program form (auto, the
+ *                                default: tile where it fits, else dataflow, else flags;
+ *                                "dataflow": the row programs only, data-flow form preferred)
+ *   "prog_waves"  "1".."8"       waves per workgroup of the dataflow / flags forms
+ *   "prog_steps"  "0"            dataflow form without compact STEP records
+ *   "tile_depth"  "1".."16"      SpMV steps per hand-off of the tile form (default: modelled)
+ *   "tile_waves"  "1".."8"       waves per workgroup of the tile form (default 8)
  *   "lanes", "lane_chunks", "kernarg_ops", "shared_rows", "verbose"   diagnostics
  * A key that was never set falls back to the environment variable KKT_<KEY> (developer
  * scripts), then to the default. */
@@ -246,6 +247,24 @@ int kkt_time_pc_apply(kkt_handle h, const double *d_x, double *d_y, int reps, fl
  * and dependent phases ran (0 when the preconditioner has no such programs).  Measurement only. */
 int kkt_time_pc_sweeps(kkt_handle h, const double *d_x, double *d_y, float *ms, int *launches,
                        int64_t *phases);
+
+/* Step-locked parity hook (tests): while set, kkt_solve / kkt_solve_device with gmres or
+ * fgmres replace their Krylov basis v_0 .. v_it by the caller's vectors before inner step `it`
+ * of global step s (s < n_steps), and record what the step produced from them: the classical
+ * Gram-Schmidt coefficients h_0 .. h_it and ||w|| after the projection (h + s * (restart + 2)),
+ * and the normalised new basis vector (v_next + s * n_local).  Two implementations of GMRES
+ * separate exponentially along a trajectory; single steps from identical inputs do not
+ * (preconditioner.py:732-759 is third-party PETSc code: this pins the restatement step by step
+ * against the CPU oracle).  V holds n_steps * (restart + 1) * n_local doubles; all arrays are
+ * host memory owned by the caller and must stay valid until the hook is cleared (NULL). */
+typedef struct kkt_steplock {
+    int n_steps;
+    int restart;
+    const double *V;
+    double *h;
+    double *v_next;
+} kkt_steplock;
+int kkt_debug_set_steplock(kkt_handle h, const kkt_steplock *lock);
 
 /* Byte accounting of the stored operator ("algorithmic bytes"). */
 typedef struct kkt_info {

@@ -38,10 +38,29 @@ class RefPc(C.Structure):
                 ("schur_emin", C.c_double), ("schur_emax", C.c_double)]
 
 
+def usable_cores(cap=16):
+    """Cores this process may really use: scheduler affinity capped by the cgroup CPU quota (a
+    one-GPU box grants a share of a much larger host; OpenMP's default of one thread per visible
+    core then oversubscribes the quota and the spin-waiting team crawls)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt[0] != "max":
+            n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+    except (OSError, ValueError, IndexError):
+        pass
+    return max(1, min(n, cap))
+
+
 def load(build=True):
     if build and not os.path.exists(LIB):
         subprocess.check_call(["make", "-C", HERE])
     lib = C.CDLL(LIB)
+    if "OMP_NUM_THREADS" not in os.environ:
+        try:
+            C.CDLL("libgomp.so.1").omp_set_num_threads(usable_cores())
+        except OSError:
+            pass
     lib.ref_kkt_apply.argtypes = [C.POINTER(RefSys), f64p, f64p]
     lib.ref_pc_apply_BE.argtypes = [C.POINTER(RefPc), f64p, f64p]
     lib.ref_gmres_BE.argtypes = [C.POINTER(RefSys), C.POINTER(RefPc), f64p, f64p, C.c_int,

@@ -204,7 +204,7 @@ class _ConvergedDefault:
 
 
 def _gmres_driver(A, B, b, x, *, restart, rtol, atol, divtol, max_it, flexible,
-                  right, monitor=None, reduce=None):
+                  right, monitor=None, reduce=None, trace=None):
     """GMRES(m) / FGMRES(m), structured like ``KSPSolve_GMRES`` + ``KSPGMRESCycle``.
 
     left  (gmres default):  Krylov on B A, monitored norm ||B r||.
@@ -270,6 +270,12 @@ def _gmres_driver(A, B, b, x, *, restart, rtol, atol, divtol, max_it, flexible,
             w = w - h @ V[:it + 1]
             H[:it + 1, it] = h
             tt = vnorm(w)
+            if trace is not None:
+                # step-locked parity (tests): the state this step started from and what it
+                # produced, before the Givens update
+                trace.append(dict(its=its, it=it, V=V[:it + 1].copy(), h=np.array(h, copy=True),
+                                  tt=tt, v_next=(w / tt if tt > 0 else w).copy(), grs_it=grs[it],
+                                  x=x.copy()))
             hapbnd = min(abs(tt / grs[it]), haptol)
             hapend = tt < hapbnd
             if not hapend:
@@ -296,6 +302,8 @@ def _gmres_driver(A, B, b, x, *, restart, rtol, atol, divtol, max_it, flexible,
             it += 1
             its += 1
             res.rnorm = rn
+            if trace is not None:
+                trace[-1]["rn"] = rn
             reason = conv(rn)
             if hapend and not reason:
                 reason = DIVERGED_BREAKDOWN
@@ -565,7 +573,7 @@ class OracleSystem:
 
     # -- preconditioner.py:337-345, 658-786
     def solve(self, u_0, u_1, b_0, b_1, *, solver_parameters=None, pc_fn=None,
-              monitor=None):
+              monitor=None, trace=None):
         if solver_parameters is None:
             solver_parameters = {}
         if pc_fn is None:
@@ -599,9 +607,10 @@ class OracleSystem:
             return self.pc_apply(pc_fn, v)
 
         if ksp_type == "gmres":
-            res = gmres(A, B, b, u, right=(sp_.get("pc_side", "left") == "right"), **kw)
+            res = gmres(A, B, b, u, right=(sp_.get("pc_side", "left") == "right"), trace=trace,
+                        **kw)
         elif ksp_type == "fgmres":
-            res = fgmres(A, B, b, u, **kw)
+            res = fgmres(A, B, b, u, trace=trace, **kw)
         elif ksp_type == "minres":
             res = minres(A, B, b, u, **kw)
         else:

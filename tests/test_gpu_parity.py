@@ -70,7 +70,7 @@ def test_preconditioner_parity_many_workgroups(CN):
     # form of the persistent program agree exactly
     # ("w": the opt-in data-flow form for any row width, matrix re-read every phase)
     for var, val in (("persistent", "0"), ("prog_mode", "flags"), ("prog_mode", "w"),
-                     ("prog_mode", "flow"), ("prog_mode", "tile")):
+                     ("prog_mode", "dataflow"), ("prog_mode", "tile")):
         other = common.gpu_system(p, options={var: val}).pc_apply(
             x, common.gpu_pc(p, MASS, schur))
         assert np.array_equal(got, other), (var, val)
