@@ -237,10 +237,13 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
         lap(0, 1);
     };
 
-    for (int lev = 0; lev < A.nlevels; ++lev) {
-        const TileLevel &L = levels[lev];
-        // ---- operands of the level: matrix values (re-loaded only when the pointer changes,
-        // i.e. per level in mode G, once in mode S), diagonal, right-hand side
+    // Operands of a level that live in registers through its steps: matrix values (re-loaded
+    // only when the pointer changes: per level in mode G, once in mode S), Jacobi diagonal,
+    // right-hand side.  Called for level 0 up front and for level l + 1 BEFORE the hand-off that
+    // ends level l, so that the HBM fetch (every tile asks for its slice of the next matrix at
+    // the same moment) runs under the hand-off's wait instead of after it.
+    double dinv[RPT], b[RPT];
+    auto load_level = [&](const TileLevel &L) {
         if ((const void *)L.vals != vals_key) {
             vals_key = (const void *)L.vals;
             const gcd_p vp = (gcd_p)L.vals;
@@ -253,6 +256,17 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                 for (int k = 0; k < W; ++k) v[sl][k] = gp[k] >= 0 ? vp[gp[k]] : 0.0;
             }
         }
+        const gcd_p dp = (gcd_p)L.dinv, bp = (gcd_p)L.bin;
+#pragma unroll
+        for (int sl = 0; sl < RPT; ++sl) {
+            dinv[sl] = gr[sl] >= 0 ? dp[gr[sl]] : 0.0;
+            b[sl] = gr[sl] >= 0 ? bp[gr[sl]] : 0.0;
+        }
+    };
+    if (A.nlevels > 0) load_level(levels[0]);
+
+    for (int lev = 0; lev < A.nlevels; ++lev) {
+        const TileLevel &L = levels[lev];
         if ((const void *)L.coef != coef_key) {
             coef_key = (const void *)L.coef;
             const gcd_p cp = (gcd_p)(const double *)L.coef;
@@ -260,16 +274,17 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
             for (int i = tid; i < 3 * (its - 1); i += T) scoef[i] = cp[i];
             // (the barrier after the first step of the level orders these writes before their use)
         }
-        const double post1 = L.post1, post2 = L.post2;
-        double dinv[RPT], b[RPT];
-        {
-            const gcd_p dp = (gcd_p)L.dinv, bp = (gcd_p)L.bin;
+        // Everything loaded for the level is pinned in registers here: a value whose load is
+        // conditional would otherwise be waited for at its first use INSIDE the step loop
+        // (s_waitcnt vmcnt(0) there would also drain whatever the loop keeps in flight).
 #pragma unroll
-            for (int sl = 0; sl < RPT; ++sl) {
-                dinv[sl] = gr[sl] >= 0 ? dp[gr[sl]] : 0.0;
-                b[sl] = gr[sl] >= 0 ? bp[gr[sl]] : 0.0;
-            }
+        for (int sl = 0; sl < RPT; ++sl) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) asm volatile("" : "+v"(v[sl][k]));
+            asm volatile("" : "+v"(dinv[sl]));
+            asm volatile("" : "+v"(b[sl]));
         }
+        const double post1 = L.post1, post2 = L.post2;
         int cr;
         {
             double *Xc = X + cur * nkp, *Xo = X + (cur ^ 1) * nkp;
@@ -338,16 +353,24 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
             lds_barrier();
             cur ^= 1;
         }
+#pragma unroll
+        for (int sl = 0; sl < RPT; ++sl) {
+            asm volatile("" : "+v"(dinv[sl]));
+            asm volatile("" : "+v"(b[sl]));
+        }
         lap(2, 1);
         // ---- Chebyshev steps 2 .. its, `depth` of them per hand-off
+        // (row count and coefficients of a step are read from LDS one step ahead: they land with
+        // the barrier's own wait instead of in front of the step's gathers)
+        int nv_next = sn[(cr == 0 ? depth : cr) - 1];
+        double cn1 = scoef[0], cn2 = scoef[1], cn3 = scoef[2];
         for (int s = 2; s <= its; ++s) {
             if (cr == 0) {
                 handoff(s >= 3);
                 cr = depth;
             }
-            const int nv = sn[cr - 1];
-            const double cf1 = scoef[3 * (s - 2)], cf2 = scoef[3 * (s - 2) + 1],
-                         cf3 = scoef[3 * (s - 2) + 2];
+            const int nv = nv_next;
+            const double cf1 = cn1, cf2 = cn2, cf3 = cn3;
             const bool last = s == its;
             const double q1 = last ? post1 : 1.0, q2 = last ? post2 : 1.0;
             const bool has_old = s >= 3;
@@ -371,6 +394,13 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                     Xo[r] = out;
                 }
             }
+            if (s < its) {
+                const int crn = cr - 1 == 0 ? depth : cr - 1;
+                nv_next = sn[crn - 1];
+                cn1 = scoef[3 * (s - 1)];
+                cn2 = scoef[3 * (s - 1) + 1];
+                cn3 = scoef[3 * (s - 1) + 2];
+            }
             lds_barrier();
             cur ^= 1;
             --cr;
@@ -387,6 +417,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
             }
             if (lev + 1 < A.nlevels) {
                 const TileLevel &N = levels[lev + 1];
+                load_level(N);
                 if (N.n_upd > 0 && N.prev_in_lds) handoff(false);
             }
         }

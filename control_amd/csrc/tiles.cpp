@@ -153,30 +153,41 @@ bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int m
             for (int j = depth + 1; j <= TILE_MAX_DEPTH; ++j) nt[j] = nt[depth];
         }
     }
-    if (auto_depth) {
-        // modelled microseconds per dependent step: one hand-off per `d` steps plus the local
-        // steps, whose cost grows with the rows per thread of the largest tile
-        double best = 1e300;
-        int best_d = 0;
-        for (int d = 1; d <= TILE_MAX_DEPTH; ++d) {
-            int64_t mk = 0, mr = 0, mh = 0;
-            for (int t = 0; t < ntiles; ++t) {
-                const int32_t *nt = &out.n[(size_t)t * (TILE_MAX_DEPTH + 1)];
-                mk = std::max<int64_t>(mk, nt[d]);
-                mr = std::max<int64_t>(mr, nt[d - 1]);
-                mh = std::max<int64_t>(mh, nt[d] - nt[0]);
-            }
-            int rp = (int)((mr + threads - 1) / threads);
-            while ((int64_t)(rp + 1) * threads < mh) ++rp;
-            if (mk > 65535 || rp > max_rpt) break;
-            const double handoff = 2.5 + 0.5 * (double)mh / threads;
-            const double step = 0.10 + 0.10 * (double)mr / threads;
-            const double per = (handoff + d * step) / d;
-            if (per < best) {
-                best = per;
-                best_d = d;
-            }
+    // Modelled microseconds per dependent step: one hand-off per `d` steps plus the local steps
+    // (fitted to per-tile timings on MI355X, 256^2 P1, depths 2 .. 10, DESIGN.md section 6: a
+    // hand-off costs 1.5 us + 1.9 us per 1 000 granule pairs gathered -- the newest iterate on all
+    // rings, the previous one on all but the outermost --, a local step 0.30 us + 0.23 us per
+    // 1 000 rows computed; 1 024-thread workgroups: 1.3 + 2.6 and 0.37 + 0.06).
+    auto model = [&](int d, double *us) -> bool {
+        int64_t mk = 0, mr = 0, mh = 0, mo = 0;
+        for (int t = 0; t < ntiles; ++t) {
+            const int32_t *nt = &out.n[(size_t)t * (TILE_MAX_DEPTH + 1)];
+            mk = std::max<int64_t>(mk, nt[d]);
+            mr = std::max<int64_t>(mr, nt[d - 1]);
+            mh = std::max<int64_t>(mh, nt[d] - nt[0]);
+            mo = std::max<int64_t>(mo, nt[d - 1] - nt[0]);
         }
+        int rp = (int)((mr + threads - 1) / threads);
+        while ((int64_t)(rp + 1) * threads < mh) ++rp;
+        if (mk > 65535 || rp > max_rpt) return false;
+        const bool big = threads > 512;
+        const double handoff = (big ? 1.3 : 1.5) + (big ? 2.6e-3 : 1.9e-3) * (double)(mh + mo);
+        const double step = big ? 0.37 + 0.06e-3 * (double)mr : 0.30 + 0.23e-3 * (double)mr;
+        *us = (handoff + d * step) / d;
+        return true;
+    };
+    if (auto_depth) {
+        // the optimum is flat: the shallowest depth within 3 % of the best (fewer redundant rows,
+        // smaller rings) is taken
+        double best = 1e300, per[TILE_MAX_DEPTH + 1];
+        int n_ok = 0, best_d = 0;
+        for (int d = 1; d <= TILE_MAX_DEPTH; ++d) {
+            if (!model(d, &per[d])) break;
+            best = std::min(best, per[d]);
+            n_ok = d;
+        }
+        for (int d = 1; d <= n_ok && !best_d; ++d)
+            if (per[d] <= 1.03 * best) best_d = d;
         if (best_d == 0) return false;
         depth = best_d;
         out.depth = depth;
@@ -186,6 +197,7 @@ bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int m
             local[t].resize(nt[depth]);
         }
     }
+    if (!model(depth, &out.model_us)) return false;
     int64_t max_nk = 0, max_rows = 0, max_halo = 0, max_own = 0;
     double red = 0.0;
     for (int t = 0; t < ntiles; ++t) {

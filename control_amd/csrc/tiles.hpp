@@ -38,6 +38,7 @@ struct TilePlan {
     uint16_t *d_lcol = nullptr;
     int64_t max_own = 0, max_rows = 0, max_halo = 0;   // statistics (largest tile)
     double mean_redundancy = 0.0;                      // mean n[depth-1] / n[0]
+    double model_us = 0.0;                             // modelled microseconds per dependent step
     void upload();
     void release();
 };
