@@ -80,11 +80,8 @@ def build_problem(args):
     blocks = instationary_blocks(sd.M, sd.K, tau, args.beta, args.n_t, CN, share=True)
     schur = (args.schur_its, args.schur_emin, args.schur_emax)
     if getattr(args, "schur_auto", False):
-        from control_amd.control import suggest_chebyshev
-        shift = (0.5 * tau if CN else tau) / args.beta**0.5
-        schur = tuple(suggest_chebyshev(blocks[2][(1, 1)], sd.M, shift, sd.boundary))
-        print(f"[bench] suggested Chebyshev (its, emin, emax) = {schur}", file=sys.stderr,
-              flush=True)
+        # degree and one interval per sub-solve matrix from Lanczos estimates on the device
+        schur = (-1, 0.0, 0.0)
     return dict(sd=sd, tau=tau, beta=args.beta, n_t=args.n_t, CN=CN, m=blocks[4],
                 blocks=blocks[:4], nodes=sd.boundary, mass=(20,) + mass_bounds, schur=schur,
                 share_values=(args.mode == "S"))
@@ -273,8 +270,8 @@ def main():
     ap.add_argument("--schur-emin", type=float, default=0.0007)
     ap.add_argument("--schur-emax", type=float, default=2.1)
     ap.add_argument("--schur-auto", action="store_true",
-                    help="sweeps and interval from control_amd.control.suggest_chebyshev "
-                         "(spectrum of the interior-level sub-solve matrix) instead of the flags")
+                    help="degree and per-matrix intervals of the sub-solves from spectrum "
+                         "estimates on the device (kkt_pc_desc.schur_its = -1) instead of the flags")
     ap.add_argument("--spmv-reps", type=int, default=50)
     ap.add_argument("--cpu-its", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -75,12 +75,10 @@ class GpuBackend:
         mb = self._mb
         schur = self.schur
         if isinstance(schur, str):
-            # "auto": the matrix of the interior time levels (the first and last levels carry a
-            # smaller shift -- control.py:2241-2327 -- and a wider spectrum; they are 2 of n_t)
-            shift = {"stationary": 1.0 / np.sqrt(beta), "BE": tau / np.sqrt(beta),
-                     "CN": 0.5 * tau / np.sqrt(beta)}[kind]
-            schur = suggest_chebyshev(block_10[(0, 0)], M, shift, nodes)
-            self.resolved_schur = schur
+            # "auto": degree and one interval per sub-solve matrix from Lanczos estimates on the
+            # device (kkt_pc_desc: schur_its = -1, schur_emin = 0); the first and last time levels
+            # carry smaller shifts (control.py:2241-2327) and get their own, wider, intervals
+            schur = (-1, 0.0, 0.0)
         return mb.SchurPC(kind=kind, M=M, beta=beta, bc_nodes=nodes,
                           mass=mb.ChebSpec(20, *lambda_v_bounds),      # control.py:1967-1982
                           schur=mb.ChebSpec(*schur), n_t=n_t, tau=tau, epsilon=epsilon)
@@ -90,7 +88,7 @@ class GpuBackend:
         """Sweeps on ``K_p``: as given, or (``"auto"``) degree and lower bound of the velocity
         sub-solves on [emin, 2.1] (P1 pressure stiffness, Jacobi-scaled)."""
         if isinstance(self.kp, str):
-            return (inner_pc.schur.its, inner_pc.schur.emin, 2.1)
+            return (-1, 0.0, 0.0)       # kkt_pc_stokes_desc: follow the inner sub-solves
         return self.kp
 
     def construct_stokes_pc(self, th, blocks, n_t, tau, beta, CN, lambda_v_bounds,

@@ -1486,6 +1486,101 @@ __global__ __launch_bounds__(256) void pc_rows_shared_g(const RowOp *__restrict_
     }
 }
 
+// KKT operator apply with shared values ("mode S", time-invariant blocks): block rows whose
+// terms use the same matrices in the same order -- the interior rows of the BE / CN stencils,
+// control.py:2907-2978 -- differ only in the vectors they read and write.  One thread loads the
+// indices and values of its two rows once per term and serves up to NB block rows with them
+// (SpMM shape: the per-non-zero load issue drops from index + value + gather to
+// gather + (index + value) / NB).  Every block row keeps the fma chain of kkt_spmv_rows (terms
+// in order, CSR order inside a term): bit-identical results.
+// `groups[g]` = {first op, count <= NB} of a run of RowOps with identical structure.
+template <int W, int NB>
+__global__ __launch_bounds__(256) void kkt_spmv_rows_shared(const RowOp *__restrict__ ops,
+                                                            const int2 *__restrict__ groups,
+                                                            const Bases bases) {
+    constexpr int R = 2, C = 128;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + wave;
+    const int2 grp = groups[blockIdx.y];
+    const int g0 = grp.x, nb = grp.y;
+    const RowOp &op0 = ops[g0];
+    if (s >= op0.nslices) return;
+    const size_t base = (size_t)s * W * C + (size_t)lane * R;
+    const int r0 = s * C + lane;
+    const int nrows = op0.nrows;
+    double acc[NB][R];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[b][q] = 0.0;
+    const gci_p colp = (gci_p)op0.col + base;
+    int c[W][R];
+    if (op0.nterms > 0) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) load_cols<R>(colp + (size_t)k * C, c[k]);
+    }
+    for (int t = 0; t < op0.nterms; ++t) {
+        const gcd_p vp = (gcd_p)op0.t[t].vals + base;
+        double v[W][R];
+#pragma unroll
+        for (int k = 0; k < W; ++k) load_vals<R, false>(vp + (size_t)k * C, v[k]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (b >= nb) break;
+            const gcd_p x = resolve(ops[g0 + b].t[t].x, bases);
+            double xv[W][R];
+#pragma unroll
+            for (int k = 0; k < W; ++k)
+#pragma unroll
+                for (int q = 0; q < R; ++q) xv[k][q] = x[c[k][q]];
+#pragma unroll
+            for (int k = 0; k < W; ++k)
+#pragma unroll
+                for (int q = 0; q < R; ++q) acc[b][q] = __builtin_fma(v[k][q], xv[k][q], acc[b][q]);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (b >= nb) break;
+        const RowOp &op = ops[g0 + b];
+        const gcd_p pa = resolve(op.yin, bases), pb = resolve(op.z, bases),
+                    pc = resolve(op.mx, bases);
+        const gcb_p rowmask = (gcb_p)op.rowmask;
+        const gd_p y = (gd_p)resolve(op.y, bases);
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int r = r0 + 64 * q;
+            if (r >= nrows) continue;
+            const bool masked = rowmask != nullptr && rowmask[r] != 0;
+            double out;
+            if (masked) {
+                out = pc ? op.malpha * pc[r] : 0.0;
+            } else {
+                double vv = op.ca * acc[b][q];
+                if (pa) vv += op.cy * pa[r];
+                if (pb) vv += op.cz * pb[r];
+                out = vv;
+            }
+            y[r] = out;
+        }
+    }
+}
+
+bool launch_rowops_grouped(hipStream_t s, const RowOp *d_ops, const int32_t *d_groups, int ngroups,
+                           int max_slices, int R, int uniform_w, const Bases &bases) {
+    constexpr int NB = 4;
+    if (R != 2 || ngroups <= 0) return false;
+    const dim3 grid((max_slices + 3) / 4, ngroups), block(256);
+    const int2 *g = reinterpret_cast<const int2 *>(d_groups);
+    switch (uniform_w) {
+#define KKT_W(n) case n: hipLaunchKernelGGL((kkt_spmv_rows_shared<n, NB>), grid, block, 0, s, d_ops, g, bases); return true;
+        KKT_W(1) KKT_W(2) KKT_W(3) KKT_W(4) KKT_W(5) KKT_W(6) KKT_W(7) KKT_W(8)
+#undef KKT_W
+        default: return false;
+    }
+}
+
 bool launch_rowops_shared(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, int R,
                           int uniform_w) {
     constexpr int NB = 4;

@@ -62,6 +62,12 @@ void launch_rowops(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, 
 bool launch_rowops_shared(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, int R,
                           int uniform_w);
 
+// Operator apply for shared values: d_groups[g] = {first op, count <= 4} of runs of EPI_LIN RowOps
+// with identical structure (same pattern, same term matrices); fixed slice widths 1..8, R = 2.
+constexpr int ROW_GROUP_MAX = 4;
+bool launch_rowops_grouped(hipStream_t s, const RowOp *d_ops, const int32_t *d_groups, int ngroups,
+                           int max_slices, int R, int uniform_w, const Bases &bases);
+
 // One persistent launch that runs `nphases` single-block RowOps in order, workgroup j
 // waiting before each phase for the workgroups d_dep[2j] .. d_dep[2j+1] (kernels.hip).
 int prog_flag_words(int nwg);

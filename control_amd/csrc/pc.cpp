@@ -29,9 +29,10 @@ SchurPC::SchurPC(System &S, const kkt_pc_desc &d) : S_(S), d_(d) {
     lo_ = S.sharded ? S.lo : 0;
     hi_ = S.sharded ? S.hi : n_;
     if (d.kind != KKT_PC_STATIONARY && n_ < 2) fail(KKT_ERR_ARG, "need at least two blocks");
-    if (d.mass_its < 0 || d.schur_its < 0) fail(KKT_ERR_ARG, "negative Chebyshev degree");
+    // schur_its == -1: degree from the spectrum; schur_emin <= 0: interval from the spectrum
+    if (d.mass_its < 0 || d.schur_its < -1) fail(KKT_ERR_ARG, "negative Chebyshev degree");
     if ((d.mass_its > 0 && !(d.mass_emax > d.mass_emin && d.mass_emin > 0)) ||
-        (d.schur_its > 0 && !(d.schur_emax > d.schur_emin && d.schur_emin > 0)))
+        (d.schur_emin > 0 && !(d.schur_emax > d.schur_emin)))
         fail(KKT_ERR_ARG, "Chebyshev bounds must satisfy 0 < emin < emax");
     // deep copies: the caller's arrays are not kept (kkt.h conventions)
     m_indptr_.assign(d.m_indptr, d.m_indptr + nx_ + 1);
@@ -113,6 +114,9 @@ void SchurPC::values_changed() {
         build_BE();
     else
         build_CN();
+    if (S_.opt("verbose") && d_.schur_emin <= 0)
+        std::fprintf(stderr, "[kkt] Chebyshev sub-solves: degree %d; %lld Lanczos steps spent on "
+                     "%zu matrices\n", schur_its_, (long long)spectrum_steps_, mats_.size());
     fuse_programs();
 }
 
@@ -285,7 +289,7 @@ bool SchurPC::prepare_tiles() {
     }
     TilePlan &tp = tile_plan_;
     if (!tp.symmetric || !tile_sweep_available(tp.W, tp.rpt, threads)) return false;
-    const size_t lds = tile_sweep_lds_bytes(tp.nk_pad, std::max(d_.schur_its, 2));
+    const size_t lds = tile_sweep_lds_bytes(tp.nk_pad, std::max(schur_its_, 2));
     if (tp.ntiles > tile_sweep_max_tiles(tp.W, tp.rpt, threads, lds)) return false;
     tp.upload();
     const size_t words = 2 * (size_t)P.nrows;
@@ -610,8 +614,54 @@ SchurPC::Mat SchurPC::schur_matrix(const double *base_vals, double c) {
     if (mask_) launch_mask_columns(st, m.vals, P.d_col, mask_, P.npadded);
     launch_extract_dinv(st, P.d_col, P.d_slice_off, m.vals, mask_, m.dinv, (int)nx_, P.nslices,
                         P.R, P.d_perm);
+    if (d_.schur_emin > 0) {
+        m.emin = d_.schur_emin;
+        m.emax = d_.schur_emax;
+    } else {
+        // Interval from the matrix itself.  Matrices with the same shift and the same values
+        // (mode G stores one copy per time level of a time-invariant operator) share one
+        // estimate; the first and last levels carry other shifts (control.py:2241-2327) and get
+        // their own, wider, intervals.
+        bool found = false;
+        for (auto &kv : mats_) {
+            if (kv.first.second != bits || kv.second.emax <= 0.0) continue;
+            unsigned *d_flag = dev_alloc<unsigned>(1);
+            HIPCHK(hipMemsetAsync(d_flag, 0, sizeof(unsigned), st));
+            launch_vals_differ(st, m.vals, kv.second.vals, P.npadded, d_flag);
+            unsigned differ = 1;
+            HIPCHK(hipMemcpyAsync(&differ, d_flag, sizeof differ, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(hipFree(d_flag));
+            if (!differ) {
+                m.emin = kv.second.emin;
+                m.emax = kv.second.emax;
+                found = true;
+                break;
+            }
+        }
+        if (!found) {
+            const Spectrum sp = jacobi_spectrum(S_, m_pat_, m.vals, m.dinv, mask_, 400);
+            spectrum_steps_ += sp.steps;
+            if (!(sp.emin > 0.0) || !(sp.emax > sp.emin))
+                fail(KKT_ERR_STATE, "sub-solve matrix is not positive definite: no Chebyshev interval");
+            m.emin = 0.85 * sp.emin;      // Ritz values lie inside the spectrum
+            m.emax = 1.05 * sp.emax;
+        }
+    }
     mats_[key] = m;
     return m;
+}
+
+// Degree of the sub-solves: as given, or 1.6 sqrt(kappa) of a typical (interior-level) matrix --
+// the measured minimum for GMRES(10) to converge on 256^2 P1 is 1.46 sqrt(kappa).
+int SchurPC::resolve_its(const Mat &typical) {
+    typical_emin_ = typical.emin;
+    typical_emax_ = typical.emax;
+    if (d_.schur_its >= 0) return d_.schur_its;
+    int its = (int)std::ceil(1.6 * std::sqrt(typical.emax / typical.emin));
+    its = std::max(4, std::min(600, its));
+    if (S_.sharded && S_.comm) its = (int)S_.comm->max_host((double)its, S_.stream);
+    return its;
 }
 
 void SchurPC::push_rows(std::vector<RowOp> &r) {
@@ -853,9 +903,10 @@ void SchurPC::build_stationary() {
     emit_solves({Solve{m_vals_, m_dinv_, b0, u0}}, d_.mass_its, d_.mass_emin, d_.mass_emax, P_, nx_);
     emit_lin({Lin{{Term{Dv, u0}}, B_, 1.0, 0.0, -1.0, nullptr, b1}});
     Mat S1 = schur_matrix(Dv, c), S2 = schur_matrix(Dz, c);
-    emit_solves({Solve{S1.vals, S1.dinv, B_, u1}}, d_.schur_its, d_.schur_emin, d_.schur_emax, P_, nx_);
+    schur_its_ = resolve_its(S1);
+    emit_solves({Solve{S1.vals, S1.dinv, B_, u1}}, schur_its_, S1.emin, S1.emax, P_, nx_);
     emit_lin({Lin{{Term{m_vals_, u1}}, B_, 1.0}});
-    emit_solves({Solve{S2.vals, S2.dinv, B_, u1}}, d_.schur_its, d_.schur_emin, d_.schur_emax, P_, nx_);
+    emit_solves({Solve{S2.vals, S2.dinv, B_, u1}}, schur_its_, S2.emin, S2.emax, P_, nx_);
 }
 
 // Time sharding: a rank owns blocks [lo, hi).  Everything that is independent
@@ -886,6 +937,10 @@ void SchurPC::build_BE() {
     for (int c = 0; c <= n_chunks; ++c) cfirst[c] = lo + (int)((int64_t)(hi - lo) * c / n_chunks);
     std::vector<int> chunk_done(n_chunks, -1);
     auto coef = [&](int i) { return i == 0 ? 0.0 : (i == n - 1 ? std::sqrt(eps) * shift : shift); };
+    {
+        const int imid = (lo + hi) / 2;      // a typical level: decides the degree when it is derived
+        schur_its_ = resolve_its(schur_matrix(block_vals(KKT_Q10, imid, imid), coef(imid)));
+    }
     auto side_chunk = [&](int c) {
         const int c0 = cfirst[c], c1 = cfirst[c + 1];
         cur_lane_ = lanes ? 1 : 0;
@@ -928,9 +983,9 @@ void SchurPC::build_BE() {
                 emit_update_and_solve(Lin{{Term{block_vals(KKT_Q10, i, i - 1),
                                                 i - 1 >= lo ? blk(u1, i - 1) : h_u1_}},
                                           blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i), nullptr},
-                                      sv, d_.schur_its, d_.schur_emin, d_.schur_emax);
+                                      sv, schur_its_, F.emin, F.emax);
             else
-                emit_solves({sv}, d_.schur_its, d_.schur_emin, d_.schur_emax, P_, nx_);
+                emit_solves({sv}, schur_its_, F.emin, F.emax, P_, nx_);
         }
     };
     if (lanes) {
@@ -966,9 +1021,9 @@ void SchurPC::build_BE() {
             emit_update_and_solve(Lin{{Term{block_vals(KKT_Q01, i, i + 1),
                                             i + 1 < hi ? blk(u1, i + 1) : h_u1_}},
                                       blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i), nullptr},
-                                  sv, d_.schur_its, d_.schur_emin, d_.schur_emax);
+                                  sv, schur_its_, G.emin, G.emax);
         else
-            emit_solves({sv}, d_.schur_its, d_.schur_emin, d_.schur_emax, P_, nx_);
+            emit_solves({sv}, schur_its_, G.emin, G.emax, P_, nx_);
     }
     if (dn >= 0) emit_comm(blk(u1, lo), dn, nullptr, -1);
 }
@@ -985,6 +1040,10 @@ void SchurPC::build_CN() {
     auto blk = [&](double *base, int i) { return base + (int64_t)(i - lo) * nx_; };
     const int up = hi < n ? S_.rank + 1 : -1, dn = lo > 0 ? S_.rank - 1 : -1;
     Mat cM = schur_matrix(nullptr, c);   // c * M~ (base absent): products with my_const * M
+    {
+        const int imid = (lo + hi) / 2;
+        schur_its_ = resolve_its(schur_matrix(block_vals(KKT_Q10, imid, imid), c));
+    }
     // (1,1)-block (1997-2014): T_1^-1 is a scan from the last block down
     if (up >= 0) emit_comm(nullptr, -1, h_t_, up);
     emit_time(T_, b0, 3, nloc, nullptr, up >= 0 ? h_t_ : nullptr);
@@ -1034,9 +1093,9 @@ void SchurPC::build_CN() {
             emit_update_and_solve(Lin{{Term{block_vals(KKT_Q10, i, i - 1), prev},
                                        Term{cM.vals, prev}},
                                       blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i), nullptr},
-                                  sv, d_.schur_its, d_.schur_emin, d_.schur_emax);
+                                  sv, schur_its_, F.emin, F.emax);
         } else {
-            emit_solves({sv}, d_.schur_its, d_.schur_emin, d_.schur_emax, P_, nx_);
+            emit_solves({sv}, schur_its_, F.emin, F.emax, P_, nx_);
         }
     }
     if (up >= 0) emit_comm(blk(u1, hi - 1), up, nullptr, -1);
@@ -1057,9 +1116,9 @@ void SchurPC::build_CN() {
             Mat H = schur_matrix(block_vals(KKT_Q01, i, i + 1), c);
             emit_update_and_solve(Lin{{Term{H.vals, i + 1 < hi ? blk(u1, i + 1) : h_u1_}},
                                       blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i), nullptr},
-                                  sv, d_.schur_its, d_.schur_emin, d_.schur_emax);
+                                  sv, schur_its_, G.emin, G.emax);
         } else {
-            emit_solves({sv}, d_.schur_its, d_.schur_emin, d_.schur_emax, P_, nx_);
+            emit_solves({sv}, schur_its_, G.emin, G.emax, P_, nx_);
         }
     }
     if (dn >= 0) emit_comm(blk(u1, lo), dn, nullptr, -1);

@@ -11,6 +11,16 @@
 
 namespace kkt {
 
+// [emin, emax] of the Jacobi-scaled matrix D^-1 A by `steps` Lanczos steps on the device
+// (spectrum.cpp); Ritz values: emin is an upper estimate of the smallest eigenvalue, emax a
+// lower estimate of the largest.
+struct Spectrum {
+    double emin, emax;
+    int steps;
+};
+Spectrum jacobi_spectrum(System &S, int pattern, const double *vals, const double *dinv,
+                         const uint8_t *rowmask, int max_steps);
+
 struct PcStep {
     enum Kind { ROWS, TIME, COPY, COMM, PROG, TILE, EV_RECORD, EV_WAIT } kind;
     int lane = 0;                   // 0: the system's stream; 1: the side stream
@@ -62,6 +72,10 @@ class SchurPC : public PcBase {
     void debug_read(unsigned long long *out, int n) override;   // diagnostic builds (KKT_STAMPS)
     void time_programs(float *ms, int *launches, int64_t *phases) override;
     int bc_set() const { return bc_set_; }
+    // degree and interval the sub-solves of a typical time level run with (given or derived)
+    int schur_its() const { return schur_its_; }
+    double typical_emin() const { return typical_emin_; }
+    double typical_emax() const { return typical_emax_; }
     int64_t n_launches() const { return (int64_t)steps_.size(); }
 
    private:
@@ -85,7 +99,12 @@ class SchurPC : public PcBase {
     struct Mat {
         double *vals;
         double *dinv;
+        double emin = 0.0, emax = 0.0;   // Chebyshev interval of this matrix (given or estimated)
     };
+    int schur_its_ = 0;                  // degree of the sub-solves (given or derived)
+    double typical_emin_ = 0.0, typical_emax_ = 0.0;
+    int resolve_its(const Mat &typical);
+    int64_t spectrum_steps_ = 0;         // Lanczos steps spent on estimates (reported when verbose)
     std::map<std::pair<const double *, uint64_t>, Mat> mats_;
     double *h_u0_ = nullptr, *h_u1_ = nullptr, *h_t_ = nullptr;   // one-block halos
     std::vector<PcStep> steps_;

@@ -126,8 +126,10 @@ StokesPC::StokesPC(System &outer, System &inner, System &commutator, const kkt_p
         fail(KKT_ERR_ARG, "inner (velocity) system has the wrong size");
     if (commutator.n_local != 2 * (int64_t)n_ * np_)
         fail(KKT_ERR_ARG, "commutator (pressure) system has the wrong size");
-    if (d.kp_its < 0 || d.mp_its < 0) fail(KKT_ERR_ARG, "negative Chebyshev degree");
-    if ((d.kp_its > 0 && !(d.kp_emax > d.kp_emin && d.kp_emin > 0)) ||
+    // kp_its == -1 / kp_emin <= 0: degree and lower bound of the velocity sub-solves (the
+    // pressure Laplacian has the same h-dependence), upper bound from K_p itself
+    if (d.kp_its < -1 || d.mp_its < 0) fail(KKT_ERR_ARG, "negative Chebyshev degree");
+    if ((d.kp_emin > 0 && !(d.kp_emax > d.kp_emin)) ||
         (d.mp_its > 0 && !(d.mp_emax > d.mp_emin && d.mp_emin > 0)))
         fail(KKT_ERR_ARG, "Chebyshev bounds must satisfy 0 < emin < emax");
     sB_ = d.b_scale;
@@ -173,7 +175,21 @@ StokesPC::StokesPC(System &outer, System &inner, System &commutator, const kkt_p
         }
         lin_.push_back(upload_launch(P, ops));
     }
-    emit_cheb(kp_steps_, Kp_, d.kp_its, d.kp_emin, d.kp_emax, h_, m_);
+    int kp_its = d.kp_its;
+    double kp_emin = d.kp_emin, kp_emax = d.kp_emax;
+    if (kp_its < 0 || kp_emin <= 0) {
+        const SchurPC *sp = dynamic_cast<const SchurPC *>(inner.pc.get());
+        if (!sp) fail(KKT_ERR_STATE, "automatic K_p sweeps need the built-in preconditioner on the inner system");
+        if (kp_its < 0) kp_its = sp->schur_its();
+        if (kp_emin <= 0) {
+            kp_emin = sp->typical_emin();
+            // K_p is singular (constants): only the upper end of its spectrum is estimated
+            kp_emax = 1.05 * jacobi_spectrum(S_, Kp_.pat, Kp_.vals, Kp_.dinv, nullptr, 60).emax;
+            if (!(kp_emax > kp_emin)) fail(KKT_ERR_STATE, "no Chebyshev interval for K_p");
+        }
+    }
+    kp_its_ = kp_its;
+    emit_cheb(kp_steps_, Kp_, kp_its, kp_emin, kp_emax, h_, m_);
     emit_cheb(mp_steps_, Mp_, d.mp_its, d.mp_emin, d.mp_emax, g_, out_ + n0);
     HIPCHK(hipStreamSynchronize(S_.stream));
 }

@@ -50,7 +50,10 @@ System::~System() {
         F(b.d_mask);
         F(b.d_idx);
     }
-    for (auto &l : apply_launches) F(l.d_ops);
+    for (auto &l : apply_launches) {
+        F(l.d_ops);
+        F(l.d_groups);
+    }
     F(d_mask_jobs);
     F(d_mask_jobs_one);
     F(d_pc_in);
@@ -559,6 +562,61 @@ void System::finalize() {
             else if (L.uniform_w != op.uniform_w)
                 L.uniform_w = -1;
         }
+        // Shared values ("mode S"): ops whose terms use the same matrices in the same order are
+        // made neighbours and served four at a time by the SpMM-shaped kernel
+        // (kkt_spmv_rows_shared); pointless when every block has its own values (mode G).
+        {
+            auto same = [](const RowOp &a, const RowOp &b) {
+                if (a.col != b.col || a.nterms != b.nterms || a.nslices != b.nslices ||
+                    a.nrows != b.nrows || a.uniform_w != b.uniform_w || a.rowmask != b.rowmask ||
+                    a.perm != b.perm)
+                    return false;
+                for (int t = 0; t < a.nterms; ++t)
+                    if (a.t[t].vals != b.t[t].vals) return false;
+                return true;
+            };
+            std::vector<RowOp> &ops = waves[w];
+            std::vector<int> order;
+            std::vector<char> used(ops.size(), 0);
+            std::vector<int32_t> groups;
+            const char *sg = opt("shared_rows");
+            const bool allow = !(sg && sg[0] == '0') && L.R == 2 && L.uniform_w >= 1 &&
+                               L.uniform_w <= 8;
+            bool uniform_all = allow;
+            for (const RowOp &op : ops) uniform_all = uniform_all && op.nterms > 0 && op.perm == nullptr;
+            if (uniform_all) {
+                for (size_t i = 0; i < ops.size(); ++i) {
+                    if (used[i]) continue;
+                    std::vector<int> run{(int)i};
+                    used[i] = 1;
+                    for (size_t j = i + 1; j < ops.size(); ++j)
+                        if (!used[j] && same(ops[i], ops[j])) {
+                            run.push_back((int)j);
+                            used[j] = 1;
+                        }
+                    for (size_t q = 0; q < run.size(); q += ROW_GROUP_MAX) {
+                        const int cnt = (int)std::min<size_t>(ROW_GROUP_MAX, run.size() - q);
+                        groups.push_back((int32_t)order.size());
+                        groups.push_back(cnt);
+                        for (int e = 0; e < cnt; ++e) order.push_back(run[q + e]);
+                    }
+                }
+                if (groups.size() / 2 < ops.size()) {      // something is shared
+                    std::vector<RowOp> sorted;
+                    std::vector<int> new_index(ops.size());
+                    for (size_t q = 0; q < order.size(); ++q) {
+                        sorted.push_back(ops[order[q]]);
+                        new_index[order[q]] = (int)q;
+                    }
+                    for (auto &kv : block_term)
+                        if (std::get<0>(kv.second) == (int)w)
+                            std::get<1>(kv.second) = new_index[std::get<1>(kv.second)];
+                    ops.swap(sorted);
+                    L.d_groups = dev_upload(groups.data(), groups.size());
+                    L.ngroups = (int)groups.size() / 2;
+                }
+            }
+        }
         L.d_ops = dev_upload(waves[w].data(), waves[w].size());
         apply_launches.push_back(L);
     }
@@ -685,6 +743,7 @@ void System::update_block_values(int q, int i, int j, const double *vals) {
     if (op.t[t].vals != d_old) fail(KKT_ERR_STATE, "apply plan out of step with the block table");
     op.t[t].vals = d_new;
     HIPCHK(hipMemcpy(apply_launches[L].d_ops + o, &op, sizeof(RowOp), hipMemcpyHostToDevice));
+    apply_launches[L].ngroups = 0;   // the op left its group of equal structure: plain kernel
     pc_stale = true;
 }
 
@@ -703,8 +762,13 @@ void System::apply(const double *d_x, double *d_y) {
     }
     if (sharded) comm_exchange_x_halos(*this, xin);
     Bases B{{xin, d_y, d_halo_x0_lo, d_halo_x1_hi}};
-    for (const RowLaunch &L : apply_launches)
+    for (const RowLaunch &L : apply_launches) {
+        if (L.ngroups > 0 &&
+            launch_rowops_grouped(stream, L.d_ops, L.d_groups, L.ngroups, L.max_slices, L.R,
+                                  L.uniform_w, B))
+            continue;
         launch_rowops(stream, L.d_ops, L.nops, L.max_slices, L.R, B, 0, L.uniform_w);
+    }
     if (CN) {
         if (sharded) comm_exchange_row_halos(*this, d_y);
         for (const TimeGroup &g : time_groups) {

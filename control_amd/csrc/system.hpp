@@ -99,6 +99,8 @@ struct RowLaunch {
     int uniform_w = -1;   // > 0: every op with terms in this launch has this slice width
     bool single = false;  // nops == 1: h_op rides in the kernel arguments
     bool shared_matrix = false;   // every op has one term with the same matrix
+    int32_t *d_groups = nullptr;  // operator apply, shared values: runs of ops of one structure
+    int ngroups = 0;
     RowOp h_op;
 };
 

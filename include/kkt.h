@@ -159,8 +159,9 @@ typedef struct kkt_pc_desc {
     const int32_t *bc_idx;
     int mass_its;
     double mass_emin, mass_emax;
-    int schur_its;
-    double schur_emin, schur_emax;
+    int schur_its;       /* -1: 1.6 sqrt(emax / emin) of a typical time level's matrix */
+    double schur_emin, schur_emax;   /* schur_emin <= 0: per matrix, from a Lanczos estimate of its
+                                        Jacobi-scaled spectrum on the device (spectrum.cpp) */
 } kkt_pc_desc;
 
 int kkt_set_pc_schur(kkt_handle h, const kkt_pc_desc *desc);
@@ -186,8 +187,10 @@ typedef struct kkt_pc_stokes_desc {
     const double *kp_values;
     const int32_t *mp_indptr, *mp_indices;    /* M_p: np x np */
     const double *mp_values;
-    int kp_its;              /* Jacobi-Chebyshev steps replacing the BoomerAMG cycle on K_p */
-    double kp_emin, kp_emax;
+    int kp_its;              /* Jacobi-Chebyshev steps replacing the BoomerAMG cycle on K_p;
+                                -1: the degree of the inner system's sub-solves */
+    double kp_emin, kp_emax; /* kp_emin <= 0: lower bound of the inner sub-solves, upper bound
+                                estimated from K_p */
     int mp_its;              /* control.py:957-971: 20 (0: one Jacobi application, :973-979) */
     double mp_emin, mp_emax;
 } kkt_pc_stokes_desc;

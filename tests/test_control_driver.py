@@ -784,6 +784,6 @@ def test_gpu_backend_default_parameters_converge():
     be = GpuBackend()
     ksp = ctl.linear_solve(solver_parameters=common.MMS_SOLVER_PARAMETERS,
                            lambda_v_bounds=(0.5, 2.0), backend=be)
-    assert ksp.getConvergedReason() > 0 and be.resolved_schur[0] >= 8
+    assert ksp.getConvergedReason() > 0
     ev, ez = common.mms_errors(ctl, disc, ref_v, ref_zeta)
     assert ev < 1e-2 and ez < 1e-2

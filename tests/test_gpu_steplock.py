@@ -84,7 +84,9 @@ def test_every_krylov_step_from_the_oracle_state(ksp, side, CN):
     # (host-side Givens recurrences on h that agrees to 1e-15, and the restart norms from each
     # side's own iterate: the relative deviation grows from 1e-15 to 1.2e-9 over the 25 steps on
     # the BE system with right preconditioning)
-    assert np.max(np.abs(hg - ho) / ho) < 1e-8
+    # (CN converges to round-off within the 25 steps: norms of 1e-12 ||r_0|| carry no digits, so
+    # the bar is relative to the norm itself and to the first one)
+    assert np.all(np.abs(hg - ho) <= 1e-8 * ho + 1e-11 * ho[0])
     assert common.rel_err(ug, uo) < 1e-8
 
 
