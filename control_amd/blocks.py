@@ -144,7 +144,10 @@ def instationary_blocks(M, K: Sequence, tau: float, beta: float, n_t: int,
         K = [K] * n_t
     if len(K) != n_t:
         raise ValueError("need one forward-operator matrix per time level")
-    K = [_csr(k) for k in K]
+    # one CSR object per distinct input matrix: a time-invariant operator (one matrix repeated)
+    # then gives one block object per coefficient pair, and the device shares its values
+    uniq = {}
+    K = [uniq.setdefault(id(k), _csr(k)) for k in K]
     cache = {}
 
     def comb(a, i, b, transpose=False):

@@ -675,9 +675,9 @@ __device__ __forceinline__ void hoist_prepare(Hoist<R> &h, const RowOp &op, cons
 }
 
 template <int R, int WFIX>
-__global__ __launch_bounds__(512) void pc_row_program(const RowOp *__restrict__ ops, int nphases,
-                                                       const int2 *__restrict__ dep,
-                                                       unsigned *flags, unsigned *err) {
+__device__ __forceinline__ void row_program_body(const RowOp *__restrict__ ops, int nphases,
+                                                 const int2 *__restrict__ dep, unsigned *flags,
+                                                 unsigned *err) {
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     const int wpw = blockDim.x >> 6;
@@ -752,6 +752,24 @@ __global__ __launch_bounds__(512) void pc_row_program(const RowOp *__restrict__ 
     }
 }
 #undef KKT_FSTAGE
+
+template <int R, int WFIX>
+__global__ __launch_bounds__(512) void pc_row_program(const RowOp *__restrict__ ops, int nphases,
+                                                       const int2 *__restrict__ dep,
+                                                       unsigned *flags, unsigned *err) {
+    row_program_body<R, WFIX>(ops, nphases, dep, flags, err);
+}
+// The same program held to 168 registers (three waves per SIMD, 3 072 wave slots on 256 CUs):
+// for blocks with more than 2 048 slices of 128 rows -- 512^2 P1, the 64^3 blocks of BASELINE
+// configs[3] -- every wave of the persistent launch must be resident, and two waves per SIMD at
+// full register use are 2 048.
+template <int R, int WFIX>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void pc_row_program_lo(const RowOp *__restrict__ ops, int nphases, const int2 *__restrict__ dep,
+                       unsigned *flags, unsigned *err) {
+    row_program_body<R, WFIX>(ops, nphases, dep, flags, err);
+}
+
 
 // Data-flow form for structures without a small fixed width (P2 / Q2 / 3-D P1): the phases
 // of pc_row_program with the hand-off of pc_row_program_g -- gathers poll tagged granules in
@@ -1222,8 +1240,15 @@ void launch_row_program_gw(hipStream_t s, const RowOp *d_ops, int nphases, int n
 int prog_flag_words(int nwg) { return nwg * FLAG_STRIDE; }
 
 typedef void (*prog_fn)(const RowOp *, int, const int2 *, unsigned *, unsigned *);
-static prog_fn pick_program(int R, int uniform_w) {
+static prog_fn pick_program(int R, int uniform_w, bool lowreg = false) {
     if (R != 2) return pc_row_program<1, 0>;
+    if (lowreg) {
+        switch (uniform_w) {
+            case 5: return pc_row_program_lo<2, 5>;
+            case 7: return pc_row_program_lo<2, 7>;
+            default: return nullptr;
+        }
+    }
     switch (uniform_w) {
 #define KKT_W(n) case n: return pc_row_program<2, n>;
         KKT_W(1) KKT_W(2) KKT_W(3) KKT_W(4) KKT_W(5) KKT_W(6) KKT_W(7) KKT_W(8)
@@ -1236,11 +1261,12 @@ static prog_fn pick_program(int R, int uniform_w) {
 // Workgroups of 64*waves_per_wg threads that are certainly co-resident on this device
 // (occupancy query of the chosen instantiation, at most 4 per CU: MI355X_MICROARCH.md,
 // residency and cooperative launch).
-int row_program_max_wgs(int R, int uniform_w, int waves_per_wg) {
+int row_program_max_wgs(int R, int uniform_w, int waves_per_wg, bool lowreg) {
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_program(R, uniform_w),
+    if (!pick_program(R, uniform_w, lowreg)) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_program(R, uniform_w, lowreg),
                                                      64 * waves_per_wg, 0) != hipSuccess)
         return 0;
     if (per_cu > 4) per_cu = 4;
@@ -1249,11 +1275,11 @@ int row_program_max_wgs(int R, int uniform_w, int waves_per_wg) {
 
 void launch_row_program(hipStream_t s, const RowOp *d_ops, int nphases, int nwg, int waves_per_wg,
                         int R, int uniform_w, const int32_t *d_dep, unsigned *d_flags,
-                        unsigned *d_err) {
+                        unsigned *d_err, bool lowreg) {
     if (nphases <= 0 || nwg <= 0) return;
     (void)hipMemsetAsync(d_flags, 0, (size_t)prog_flag_words(nwg) * sizeof(unsigned), s);
     const dim3 grid(nwg), block(64 * waves_per_wg);
-    hipLaunchKernelGGL(pick_program(R, uniform_w), grid, block, 0, s, d_ops, nphases,
+    hipLaunchKernelGGL(pick_program(R, uniform_w, lowreg), grid, block, 0, s, d_ops, nphases,
                        reinterpret_cast<const int2 *>(d_dep), d_flags, d_err);
 }
 

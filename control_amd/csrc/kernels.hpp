@@ -87,7 +87,7 @@ static_assert(sizeof(PhaseLite) == 64, "one scalar cache line");
 void launch_row_program_g(hipStream_t s, const RowOp *d_ops, const PhaseLite *d_lite, int nphases,
                           int nwg, int waves_per_wg, int uniform_w, unsigned long long *g0,
                           unsigned long long *g1, size_t granule_words, unsigned *d_err);
-int row_program_max_wgs(int R, int uniform_w, int waves_per_wg);
+int row_program_max_wgs(int R, int uniform_w, int waves_per_wg, bool lowreg = false);
 // data-flow form for any width (R = 2): granule hand-off, matrix re-read from L2 every phase
 int row_program_gw_max_wgs(int waves_per_wg);
 void launch_row_program_gw(hipStream_t s, const RowOp *d_ops, int nphases, int nwg,
@@ -95,7 +95,7 @@ void launch_row_program_gw(hipStream_t s, const RowOp *d_ops, int nphases, int n
                            size_t granule_words, unsigned *d_err);
 void launch_row_program(hipStream_t s, const RowOp *d_ops, int nphases, int nwg, int waves_per_wg,
                         int R, int uniform_w, const int32_t *d_dep, unsigned *d_flags,
-                        unsigned *d_err);
+                        unsigned *d_err, bool lowreg = false);
 
 // ---- tile sweep program (tile_kernels.hip; plan: tiles.hpp)
 constexpr int TILE_DEPTH_MAX = 16;

@@ -167,6 +167,22 @@ bool SchurPC::setup_row_programs() {
                 break;
             }
         }
+        if (!wpw) {
+            // more than 2 048 slices: the counter form held to 168 registers keeps three waves
+            // per SIMD resident (kernels.hip, pc_row_program_lo)
+            // (rows of up to 8 entries only: wider ones spill at 168 registers and run slower than
+            // the plain launches -- 26.8 against 20 us per step on 64^3 P1)
+            for (int cand : {4, 8}) {
+                if (P.uniform_w < 1 || P.uniform_w > 8) break;
+                const int n = (P.nslices + cand - 1) / cand;
+                if (n <= row_program_max_wgs(P.R, P.uniform_w, cand, true)) {
+                    wpw = cand;
+                    nwg = n;
+                    prog_lowreg_ = true;
+                    break;
+                }
+            }
+        }
         if (!wpw) return false;
         // workgroup j must wait for every workgroup whose rows it gathers from, and for
         // every workgroup that gathers from its rows (write-after-read on rotating buffers)
@@ -209,7 +225,7 @@ bool SchurPC::setup_row_programs() {
                                nwg <= row_program_gw_max_wgs(wpw);
             const bool g_ok = !gw_ok && row_program_g_available(P.R, P.uniform_w) &&
                               nwg <= row_program_g_max_wgs(P.uniform_w, wpw);
-            bool want = !(pm && pm[0] == 'f') && (g_ok || gw_ok);
+            bool want = !(pm && pm[0] == 'f') && (g_ok || gw_ok) && !prog_lowreg_;
             if (want) {
                 // between waves (the unit that publishes and polls), in storage positions
                 const int64_t rw = 64 * P.R;
@@ -654,11 +670,16 @@ SchurPC::Mat SchurPC::schur_matrix(const double *base_vals, double c) {
 
 // Degree of the sub-solves: as given, or 1.6 sqrt(kappa) of a typical (interior-level) matrix --
 // the measured minimum for GMRES(10) to converge on 256^2 P1 is 1.46 sqrt(kappa).
+// Crank-Nicolson: 2.6 sqrt(kappa) -- its preconditioner wraps the sweeps in the running sums
+// T_2^-1 / T_2 over all time levels (control.py:2053, 2118), which accumulate the error of the
+// inexact sub-solves: with 1.6 sqrt(kappa) GMRES(10) stalls on 256^2 x 64, with 2.5 it needs 15
+// iterations.
 int SchurPC::resolve_its(const Mat &typical) {
     typical_emin_ = typical.emin;
     typical_emax_ = typical.emax;
     if (d_.schur_its >= 0) return d_.schur_its;
-    int its = (int)std::ceil(1.6 * std::sqrt(typical.emax / typical.emin));
+    const double factor = d_.kind == KKT_PC_INSTATIONARY_CN ? 2.6 : 1.6;
+    int its = (int)std::ceil(factor * std::sqrt(typical.emax / typical.emin));
     its = std::max(4, std::min(600, its));
     if (S_.sharded && S_.comm) its = (int)S_.comm->max_host((double)its, S_.stream);
     return its;
@@ -1180,7 +1201,7 @@ void SchurPC::replay(size_t first, size_t last) {
                                          P.uniform_w, d_g0_, d_g1_, granule_words_, d_err_);
                 else
                     launch_row_program(st, s.rows.d_ops, s.nphases, prog_nwg_, prog_wpw_, P.R,
-                                       P.uniform_w, d_dep_, d_flags_, d_err_);
+                                       P.uniform_w, d_dep_, d_flags_, d_err_, prog_lowreg_);
                 break;
             }
             case PcStep::TILE: {

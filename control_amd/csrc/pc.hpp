@@ -132,6 +132,7 @@ class SchurPC : public PcBase {
     int32_t *d_dep_ = nullptr;
     unsigned *d_flags_ = nullptr, *d_err_ = nullptr;
     bool prog_granule_ = false;
+    bool prog_lowreg_ = false;   // counter form at three waves per SIMD (> 2 048 slices)
     int prog_mode_ = 0;   // 0 counter form, 1 pc_row_program_g, 2 pc_row_program_gw
     unsigned long long *d_g0_ = nullptr, *d_g1_ = nullptr;
     size_t granule_words_ = 0;

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cctype>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -614,6 +615,10 @@ void System::finalize() {
                     ops.swap(sorted);
                     L.d_groups = dev_upload(groups.data(), groups.size());
                     L.ngroups = (int)groups.size() / 2;
+                    if (opt("verbose"))
+                        std::fprintf(stderr, "[kkt] operator apply, launch %zu: %zu block rows in %d "
+                                     "groups of equal structure (shared values)\n", w, ops.size(),
+                                     L.ngroups);
                 }
             }
         }

@@ -76,6 +76,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     // SELL array stay in registers.  Wide rows (3-D P1, P2): columns are packed two to a
     // register and the positions are re-read from memory once per level and matrix.
     constexpr bool PACK = W > 9;
+    constexpr int CH = PACK ? 5 : W;   // entries of a row handled at a time
     constexpr int WP = (W + 1) / 2;
     constexpr int CW = PACK ? WP : W, GW = PACK ? 1 : W;
     unsigned cpk[RPT][CW];
@@ -249,11 +250,17 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
             const gcd_p vp = (gcd_p)L.vals;
 #pragma unroll
             for (int sl = 0; sl < RPT; ++sl) {
-                int gp[W];
 #pragma unroll
-                for (int k = 0; k < W; ++k) gp[k] = KKT_GP(sl, k);
+                for (int k0 = 0; k0 < W; k0 += CH) {
+                    int gp[CH];
 #pragma unroll
-                for (int k = 0; k < W; ++k) v[sl][k] = gp[k] >= 0 ? vp[gp[k]] : 0.0;
+                    for (int k = 0; k < CH; ++k)
+                        if (k0 + k < W) gp[k] = KKT_GP(sl, k0 + k);
+#pragma unroll
+                    for (int k = 0; k < CH; ++k)
+                        if (k0 + k < W) v[sl][k0 + k] = gp[k] >= 0 ? vp[gp[k]] : 0.0;
+                    if constexpr (PACK) __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         const gcd_p dp = (gcd_p)L.dinv, bp = (gcd_p)L.bin;
@@ -304,16 +311,23 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
 #pragma unroll
                     for (int sl = 0; sl < RPT; ++sl) {
                         if (sl * T >= nk1) continue;
-                        int gp[W];
-                        double vu[W];
 #pragma unroll
-                        for (int k = 0; k < W; ++k) gp[k] = KKT_GP(sl, k);
+                        for (int k0 = 0; k0 < W; k0 += CH) {
+                            int gp[CH];
+                            double vu[CH];
 #pragma unroll
-                        for (int k = 0; k < W; ++k)
-                            vu[k] = (gr[sl] >= 0 && gp[k] >= 0) ? up[gp[k]] : 0.0;
+                            for (int k = 0; k < CH; ++k)
+                                if (k0 + k < W) gp[k] = KKT_GP(sl, k0 + k);
 #pragma unroll
-                        for (int k = 0; k < W; ++k)
-                            acc[sl] = __builtin_fma(vu[k], Xc[KKT_COL(sl, k)], acc[sl]);
+                            for (int k = 0; k < CH; ++k)
+                                if (k0 + k < W)
+                                    vu[k] = (gr[sl] >= 0 && gp[k] >= 0) ? up[gp[k]] : 0.0;
+#pragma unroll
+                            for (int k = 0; k < CH; ++k)
+                                if (k0 + k < W)
+                                    acc[sl] = __builtin_fma(vu[k], Xc[KKT_COL(sl, k0 + k)], acc[sl]);
+                            if constexpr (PACK) __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 }
                 const gd_p bo = (gd_p)L.bout;
@@ -381,7 +395,18 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                 const int r = sl * T + tid;
                 double acc = 0.0;
 #pragma unroll
-                for (int k = 0; k < W; ++k) acc = __builtin_fma(v[sl][k], Xc[KKT_COL(sl, k)], acc);
+                for (int k0 = 0; k0 < W; k0 += CH) {
+                    // (wide rows: a bounded number of gathers in flight, or the registers of the
+                    // matrix values spill)
+                    double xv[CH];
+#pragma unroll
+                    for (int k = 0; k < CH; ++k)
+                        if (k0 + k < W) xv[k] = Xc[KKT_COL(sl, k0 + k)];
+#pragma unroll
+                    for (int k = 0; k < CH; ++k)
+                        if (k0 + k < W) acc = __builtin_fma(v[sl][k0 + k], xv[k], acc);
+                    if constexpr (PACK) __builtin_amdgcn_sched_barrier(0);
+                }
                 if (r < nv) {
                     const double e0 = Xo[r], e1 = Xc[r];
                     double out = 0.0;
@@ -429,18 +454,23 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
 
 typedef void (*tile_fn)(const TileArgs, const TileLevel *, const int32_t *, const int32_t *,
                         const uint16_t *, const int32_t *, const uint8_t *);
-// workgroups of at most 512 threads may use 256 registers per thread; 1024-thread workgroups
-// (four row slots fewer per thread for the big tiles of 3-D meshes) 128
+// Register budget per thread by workgroup size: 512 threads -> 256, 768 -> 168, 1024 -> 128.
+// Narrow rows (2-D P1) run 512 threads with up to three row slots or 1 024 with one; wide rows
+// (3-D P1: 15 entries, 30 registers of matrix values per row slot) run 768 threads with two.
 static tile_fn pick_tile(int W, int rpt, int threads) {
-    const bool big = threads > 512;
-#define KKT_T(w)                                                                     \
-    if (W == w) {                                                                    \
-        switch (rpt) {                                                               \
-            case 1: return big ? pc_tile_sweep<w, 1, 1024> : pc_tile_sweep<w, 1, 512>; \
-            case 2: return big ? pc_tile_sweep<w, 2, 1024> : pc_tile_sweep<w, 2, 512>; \
-            case 3: return big ? nullptr : pc_tile_sweep<w, 3, 512>;                 \
-            default: return nullptr;                                                 \
-        }                                                                            \
+#define KKT_T(w)                                                                         \
+    if (W == w) {                                                                        \
+        if (threads <= 512) {                                                            \
+            switch (rpt) {                                                               \
+                case 1: return pc_tile_sweep<w, 1, 512>;                                 \
+                case 2: return pc_tile_sweep<w, 2, 512>;                                 \
+                case 3: return w <= 9 ? pc_tile_sweep<(w <= 9 ? w : 5), 3, 512> : nullptr; \
+                default: return nullptr;                                                 \
+            }                                                                            \
+        }                                                                                \
+        if (threads <= 768) return rpt == 1 ? pc_tile_sweep<w, 1, 768>                    \
+                                   : rpt == 2 ? pc_tile_sweep<w, 2, 768> : nullptr;      \
+        return rpt == 1 ? pc_tile_sweep<w, 1, 1024> : nullptr;                           \
     }
     KKT_T(5) KKT_T(7) KKT_T(9) KKT_T(15)
 #undef KKT_T
