@@ -50,7 +50,7 @@ class Info(C.Structure):
                  "nnz_blocks", "rows_blocks", "bytes_algorithmic",
                  "bytes_device_values", "bytes_device_index", "bytes_streamed")] + \
                [("last_solve_ms", C.c_double), ("last_pc_applies", C.c_int64),
-                ("last_op_applies", C.c_int64)]
+                ("last_op_applies", C.c_int64), ("program_fallbacks", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

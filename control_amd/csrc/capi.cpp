@@ -68,7 +68,8 @@ int kkt_set_option(kkt_handle h, const char *key, const char *value) {
         static const char *known[] = {"sell_r", "sell_sort", "no_graph", "persistent", "prog_mode",
                                       "prog_waves", "prog_steps", "tile_depth", "tile_waves",
                                       "lanes", "lane_chunks", "kernarg_ops", "shared_rows",
-                                      "verbose", "stamps", "tile_poll_delay"};
+                                      "verbose", "stamps", "tile_poll_delay",
+                                      "debug_drop_handoff"};
         if (!key || !value) fail(KKT_ERR_ARG, "null option");
         bool ok = false;
         for (const char *k : known) ok = ok || std::strcmp(k, key) == 0;
@@ -201,8 +202,20 @@ int kkt_pc_apply(kkt_handle h, const double *x, double *y) {
         TmpVec dx(S), dy(S);
         up(S, dx.p, x);
         S.pc_apply(dx.p, dy.p);
+        if (S.pc) {
+            // a sweep program that timed out is replaced by plain launches and the application
+            // redone (same arithmetic)
+            std::string why;
+            if (S.pc->timed_out(&why)) {
+                if (!S.pc->fallback_plain()) fail(KKT_ERR_HIP, why);
+                ++S.program_fallbacks;
+                S.info.program_fallbacks = S.program_fallbacks;
+                S.err = why + "; continued with plain launches";
+                S.pc_apply(dx.p, dy.p);
+                S.pc->check();
+            }
+        }
         down(S, dy.p, y);
-        if (S.pc) S.pc->check();
         if (S.pc_cb_failed) {
             S.pc_cb_failed = false;
             fail(KKT_ERR_CALLBACK, "Error encountered in preconditioner callback");

@@ -1062,8 +1062,36 @@ __global__ __launch_bounds__(512) void pc_row_program_g(const RowOp *__restrict_
                             ok &= (unsigned)(ga[k][q] >> 32) == ep_in &&
                                   (unsigned)(gb[k][q] >> 32) == ep_in;
                     if (__all(ok) || dead || ++spins >= PROG_SPIN_LIMIT) break;
+                    // back off: a wave that spins at full rate takes the issue slots (older wave
+                    // first, MI355X_MICROARCH.md "Two waves per SIMD") and the memory queue of
+                    // the very CU whose other waves may have to produce what it waits for
+                    __builtin_amdgcn_s_sleep(2);
                 }
                 if (!__all(ok)) {
+                    // who waited for what: a tag below the expected one means the producer has
+                    // not run (or is not resident), above it an overwritten granule
+                    if (!dead && !ok && atomicCAS(err + 1, 0u, 1u) == 0u) {
+                        bool mine = false;
+#pragma unroll
+                        for (int k = 0; k < W; ++k)
+#pragma unroll
+                            for (int q = 0; q < R; ++q) {
+                                const bool bad = (unsigned)(ga[k][q] >> 32) != ep_in ||
+                                                 (unsigned)(gb[k][q] >> 32) != ep_in;
+                                if (bad && !mine) {
+                                    mine = true;
+                                    err[24] = (unsigned)blockIdx.x;
+                                    err[25] = (unsigned)wave;
+                                    err[26] = (unsigned)lane;
+                                    err[27] = (unsigned)ph;
+                                    err[28] = ep_in;
+                                    err[29] = (unsigned)(ga[k][q] >> 32);
+                                    err[30] = (unsigned)(gb[k][q] >> 32);
+                                    err[31] = (unsigned)c[k][q];
+                                    err[32] = (unsigned)(c[k][q] / C);   // producing slice
+                                }
+                            }
+                    }
                     dead = true;
                     if (lane == 0) atomicOr(err, 2u);
                 }

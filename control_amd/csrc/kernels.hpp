@@ -125,6 +125,8 @@ struct TileArgs {
     unsigned *err;                            // word 0: error bits; words 8..: first time-out record
     int32_t stamps;                           // diagnostics: per-tile 100 MHz tick sums at err + 64
     int32_t poll_delay;                       // s_sleep units between publishing and the first poll
+    int32_t debug_drop;                       // test hook: tile 0 skips publishing hand-off number
+                                              // debug_drop (> 0), so its neighbours time out
 };
 bool tile_sweep_available(int W, int rpt, int threads);
 size_t tile_sweep_lds_bytes(int nk_pad, int its);

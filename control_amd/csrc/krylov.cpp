@@ -9,6 +9,7 @@
 // device-to-host copy per iteration (the new Hessenberg column and the norm).
 #include <chrono>
 #include <cmath>
+#include <string>
 #include <vector>
 
 #include "comm.hpp"
@@ -286,9 +287,42 @@ void System::solve_minres(const double *d_b, double *d_u, int *its_out, int *rea
     if (pc_cb_failed) fail(KKT_ERR_CALLBACK, "Error encountered in preconditioner callback");
 }
 
+namespace {
+struct ProgramTimeout {
+    std::string why;
+};
+}  // namespace
+
+// A sweep program that timed out (bounded spins; the kernel runs to its end, results invalid)
+// is not fatal: the preconditioner is rebuilt as plain launches and the solve starts over from
+// the caller's initial guess.
 void System::solve(const double *d_b, double *d_u, int *its_out, int *reason_out,
                    double *rnorm_out, double *hist, int hist_cap, int *hist_len) {
     if (!finalized) fail(KKT_ERR_STATE, "system not finalized");
+    double *u0 = nullptr;
+    if (pc) {
+        if (!d_guess) d_guess = new_vec();
+        u0 = d_guess;
+        launch_copy(stream, u0, d_u, n_local);
+    }
+    try {
+        solve_once(d_b, d_u, its_out, reason_out, rnorm_out, hist, hist_cap, hist_len);
+    } catch (const ProgramTimeout &t) {
+        if (!pc || !pc->fallback_plain()) fail(KKT_ERR_HIP, t.why);
+        ++program_fallbacks;
+        err = t.why + "; continued with plain launches";
+        launch_copy(stream, d_u, u0, n_local);
+        try {
+            solve_once(d_b, d_u, its_out, reason_out, rnorm_out, hist, hist_cap, hist_len);
+        } catch (const ProgramTimeout &t2) {
+            fail(KKT_ERR_HIP, t2.why);
+        }
+    }
+    info.program_fallbacks = program_fallbacks;
+}
+
+void System::solve_once(const double *d_b, double *d_u, int *its_out, int *reason_out,
+                        double *rnorm_out, double *hist, int hist_cap, int *hist_len) {
     if (ksp.type == KKT_KSP_MINRES)
         return solve_minres(d_b, d_u, its_out, reason_out, rnorm_out, hist, hist_cap, hist_len);
     const bool flexible = ksp.type == KKT_KSP_FGMRES;
@@ -405,6 +439,10 @@ void System::solve(const double *d_b, double *d_u, int *its_out, int *reason_out
             if (sharded) comm->allreduce_sum(d_tt + 1, 1, stream);
             launch_norm2_finish(stream, d_tt + 1, d_tt);
             read_scalars(d_hcol, it + 2);
+            if (pc) {
+                std::string why;
+                if (pc->timed_out(&why)) throw ProgramTimeout{why};
+            }
             for (int k = 0; k <= it; ++k) Hm(k, it) = h_pinned[k];
             const double tt = h_pinned[it + 1];
             const double hapbnd = std::min(std::fabs(tt / grs[it]), haptol);
@@ -481,7 +519,10 @@ void System::solve(const double *d_b, double *d_u, int *its_out, int *reason_out
     // corrected solution (preconditioner.py:761-766)
     ns_project(d_u, d_u);
     sync();
-    if (pc) pc->check();
+    if (pc) {
+        std::string why;
+        if (pc->timed_out(&why)) throw ProgramTimeout{why};
+    }
     info.last_solve_ms =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     if (its_out) *its_out = its;

@@ -151,12 +151,13 @@ bool SchurPC::setup_row_programs() {
             if (pass == 0 && cand > 1 && !(pw && cand == first) &&
                 (P.nslices + cand - 1) / cand > n_cus)
                 continue;
-            // data-flow form with two 4-wave workgroups on a CU: long programs (about 1 000
-            // phases and more; 401^2 mesh, 315 workgroups) ran into the bounded spin of a wave
-            // waiting for a neighbour (reported, results discarded).  One-wave workgroups and
-            // one 8-wave workgroup per CU are bit-identical to the plain launches over
-            // 10 000 phases, so those are the shapes used; the cause is not understood yet
-            if (try_g && cand == 4 && !(pw && first == 4)) continue;
+            // (Round 1 fenced the data-flow form with two 4-wave workgroups on a CU off: programs
+            // of about 1 000 phases on 401^2 -- 315 workgroups -- ran into the bounded spin.  Its
+            // poll loop spun at full rate; an older wave that spins takes the issue slots and the
+            // memory queue of the CU whose younger waves must produce what it waits for.  With
+            // the back-off in the poll loop the same shape reproduces the plain launches bit
+            // for bit (scripts/dbg_midsize.py 400 12 80, KKT_PROG_WAVES=4); a time-out is no
+            // longer fatal either -- the step falls back to plain launches.)
             const int n = (P.nslices + cand - 1) / cand;
             int cap = row_program_max_wgs(P.R, P.uniform_w, cand);
             if (try_g) cap = std::min(cap, row_program_g_max_wgs(P.uniform_w, cand));
@@ -540,25 +541,45 @@ void SchurPC::time_programs(float *ms, int *launches, int64_t *phases) {
     }
 }
 
-void SchurPC::check() {
-    if (!d_err_) return;
+bool SchurPC::timed_out(std::string *why) {
+    if (!d_err_) return false;
     unsigned e = 0;
     HIPCHK(hipMemcpyAsync(&e, d_err_, sizeof e, hipMemcpyDeviceToHost, S_.stream));
     HIPCHK(hipStreamSynchronize(S_.stream));
-    if (e) {
-        unsigned rec[24] = {0};
-        HIPCHK(hipMemcpy(rec, d_err_, sizeof rec, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemset(d_err_, 0, sizeof rec));
-        std::string msg = "persistent sweep kernel timed out waiting for a neighbour workgroup";
-        if (e & 4u)
-            msg += " (tile form: tile " + std::to_string(rec[8]) + ", hand-off " +
-                   std::to_string(rec[9]) + ", local row " + std::to_string(rec[10]) +
-                   ", global row " + std::to_string(rec[11]) + ", tags seen new " +
-                   std::to_string(rec[12]) + "/" + std::to_string(rec[13]) + " old " +
-                   std::to_string(rec[14]) + "/" + std::to_string(rec[15]) +
-                   (rec[16] ? ", both iterates)" : ", newest iterate only)");
-        fail(KKT_ERR_HIP, msg);
-    }
+    if (!e) return false;
+    unsigned rec[40] = {0};
+    HIPCHK(hipMemcpy(rec, d_err_, sizeof rec, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(d_err_, 0, sizeof rec));
+    std::string msg = "persistent sweep kernel timed out waiting for a neighbour workgroup";
+    if (e & 4u)
+        msg += " (tile form: tile " + std::to_string(rec[8]) + ", hand-off " +
+               std::to_string(rec[9]) + ", local row " + std::to_string(rec[10]) +
+               ", global row " + std::to_string(rec[11]) + ", tags seen new " +
+               std::to_string(rec[12]) + "/" + std::to_string(rec[13]) + " old " +
+               std::to_string(rec[14]) + "/" + std::to_string(rec[15]) +
+               (rec[16] ? ", both iterates)" : ", newest iterate only)");
+    if (e & 2u)
+        msg += " (data-flow form: workgroup " + std::to_string(rec[24]) + " wave " +
+               std::to_string(rec[25]) + " lane " + std::to_string(rec[26]) + ", phase " +
+               std::to_string(rec[27]) + ", expected tag " + std::to_string(rec[28]) +
+               ", seen " + std::to_string(rec[29]) + "/" + std::to_string(rec[30]) +
+               " at column " + std::to_string(rec[31]) + " of slice " + std::to_string(rec[32]) + ")";
+    if (e & 1u) msg += " (counter form)";
+    if (why) *why = msg;
+    return true;
+}
+
+void SchurPC::check() {
+    std::string why;
+    if (timed_out(&why)) fail(KKT_ERR_HIP, why);
+}
+
+// The same steps as plain launches (bit-identical arithmetic, tests/test_gpu_parity.py).
+bool SchurPC::fallback_plain() {
+    if (!use_programs_) return false;
+    use_programs_ = false;
+    values_changed();
+    return true;
 }
 
 const double *SchurPC::block_vals(int q, int i, int j) const {
@@ -1221,6 +1242,10 @@ void SchurPC::replay(size_t first, size_t last) {
                 a.granule_bytes = (unsigned)(words * sizeof(unsigned long long));
                 a.err = d_err_;
                 a.stamps = S_.opt("stamps") != nullptr;
+                {
+                    const char *dd = S_.opt("debug_drop_handoff");
+                    a.debug_drop = dd ? std::atoi(dd) : 0;
+                }
                 {
                     const char *pd = S_.opt("tile_poll_delay");
                     a.poll_delay = pd ? std::atoi(pd) : 24;   // ~0.7 us (measured optimum)

@@ -3,6 +3,7 @@
 // Control.Instationary.construct_pc (control.py:1943-2440).
 #pragma once
 #include <map>
+#include <string>
 #include <vector>
 
 #include "comm.hpp"
@@ -50,6 +51,11 @@ class PcBase {
     virtual double *out() = 0;
     virtual void values_changed() {}
     virtual void check() {}
+    // A persistent sweep program gave up waiting for a neighbour (bounded spins): true once,
+    // with the diagnostic record in *why.  fallback_plain() then rebuilds the preconditioner as
+    // plain launches (same arithmetic), so the caller can redo the work instead of failing.
+    virtual bool timed_out(std::string *) { return false; }
+    virtual bool fallback_plain() { return false; }
     virtual void debug_read(unsigned long long *, int) {}
     // measurement: time the persistent programs of the next run() with events
     virtual void time_programs(float *ms, int *launches, int64_t *phases) {
@@ -69,6 +75,8 @@ class SchurPC : public PcBase {
     double *out() override { return out_; }
     void values_changed() override;
     void check() override;   // throws if a persistent row program reported a time-out
+    bool timed_out(std::string *why) override;
+    bool fallback_plain() override;
     void debug_read(unsigned long long *out, int n) override;   // diagnostic builds (KKT_STAMPS)
     void time_programs(float *ms, int *launches, int64_t *phases) override;
     int bc_set() const { return bc_set_; }
@@ -219,6 +227,8 @@ class StokesPC : public PcBase {
     double *in() override { return in_; }
     double *out() override { return out_; }
     void check() override;
+    bool timed_out(std::string *why) override { return inner_.pc && inner_.pc->timed_out(why); }
+    bool fallback_plain() override { return inner_.pc && inner_.pc->fallback_plain(); }
 
    private:
     System &S_, &inner_, &comm_;

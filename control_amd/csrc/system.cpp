@@ -60,6 +60,7 @@ System::~System() {
     F(d_pc_in);
     F(d_pc_out);
     F(d_rhs);
+    F(d_guess);
     F(d_xc);
     F(d_tmp_y);
     F(d_sums);

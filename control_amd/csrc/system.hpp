@@ -163,6 +163,7 @@ struct System {
     MaskJob *d_mask_jobs_one = nullptr;   // same masks with alpha = 1 (preconditioner side)
     double *d_pc_in = nullptr, *d_pc_out = nullptr;   // callback / identity preconditioner
     double *d_rhs = nullptr;          // corrected right-hand side of a solve
+    double *d_guess = nullptr;        // the caller's initial guess (a solve may start over)
     double *d_xc = nullptr;           // ConstantNullspace-corrected copy of x
     double *d_tmp_y = nullptr;        // raw rows before the CN transform
     double *d_sums = nullptr;
@@ -231,6 +232,9 @@ struct System {
     void pc_apply_timed(const double *d_x, double *d_y, float *ms, int *launches, int64_t *phases);
     void solve(const double *d_b, double *d_u, int *its, int *reason, double *rnorm,
                double *hist, int hist_cap, int *hist_len);
+    void solve_once(const double *d_b, double *d_u, int *its, int *reason, double *rnorm,
+                    double *hist, int hist_cap, int *hist_len);
+    int program_fallbacks = 0;   // sweep programs replaced by plain launches after a time-out
     void solve_minres(const double *d_b, double *d_u, int *its, int *reason, double *rnorm,
                       double *hist, int hist_cap, int *hist_len);
     void ensure_workspace(int restart, bool flexible);

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
 #pragma unroll
         for (int sl = 0; sl < RPT; ++sl) {
             const int r = sl * T + tid;
-            if (r < n0) {
+            if (r < n0 && !(tile == 0 && A.debug_drop > 0 && (int)epoch == A.debug_drop)) {
                 publish(rn, gr[sl], Xc[r], epoch);
                 if (both) publish(ro, gr[sl], Xo[r], epoch);
             }

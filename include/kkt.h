@@ -286,6 +286,9 @@ typedef struct kkt_info {
     double last_solve_ms;       /* wall time of the last kkt_solve* Krylov loop */
     int64_t last_pc_applies;    /* preconditioner applications in the last solve */
     int64_t last_op_applies;    /* operator applications in the last solve */
+    int64_t program_fallbacks;  /* times a persistent sweep program timed out waiting for a
+                                   neighbour workgroup and the preconditioner was rebuilt as
+                                   plain launches (kkt_last_error holds the diagnostic record) */
 } kkt_info;
 int kkt_get_info(kkt_handle h, kkt_info *info);
 

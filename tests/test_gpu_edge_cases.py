@@ -255,3 +255,35 @@ def test_mid_size_mesh_long_sweep_program_matches_plain_launches():
     g2 = common.gpu_system(p, options={"persistent": "0"})
     y2 = g2.pc_apply(x, common.gpu_pc(p, p["mass"], p["schur"]))
     assert np.array_equal(y, y2)
+
+
+def test_sweep_program_timeout_falls_back_to_plain_launches():
+    """A persistent sweep program that gives up waiting for a neighbour (bounded spins) must not
+    fail the call: the preconditioner is rebuilt as plain launches and the work redone.  The test
+    hook makes tile 0 skip one hand-off, so its neighbours time out."""
+    p = common.heat_problem(n=96, n_t=6)
+    schur = (6, 0.05, 2.1)
+    x = common.rng_vector(2 * p["m"] * p["sd"].n_dofs)
+    ref = common.gpu_system(p, options={"persistent": "0"}).pc_apply(
+        x, common.gpu_pc(p, (20, 0.5, 2.0), schur))
+    g = common.gpu_system(p, options={"prog_mode": "tile", "debug_drop_handoff": "3"})
+    got = g.pc_apply(x, common.gpu_pc(p, (20, 0.5, 2.0), schur))
+    assert np.array_equal(got, ref)
+    assert g.info()["program_fallbacks"] == 1
+    msg = g._lib.kkt_last_error(g.handle).decode()
+    assert "tile form" in msg and "plain launches" in msg
+    # and inside a solve: it starts over from the caller's guess
+    g2 = common.gpu_system(p, options={"prog_mode": "tile", "debug_drop_handoff": "3"})
+    m, nx = p["m"], p["sd"].n_dofs
+    b = x.reshape(2 * m, nx)
+    sp_ = {"linear_solver": "gmres", "gmres_restart": 10, "maximum_iterations": 8,
+           "relative_tolerance": 0.0, "absolute_tolerance": 0.0, "monitor_convergence": False,
+           "preconditioner": True}
+    out = []
+    for gs in (g2, common.gpu_system(p, options={"persistent": "0"})):
+        u0, u1 = np.zeros((m, nx)), np.zeros((m, nx))
+        gs.solve(u0, u1, b[:m].copy(), b[m:].copy(), solver_parameters=sp_,
+                 pc_fn=common.gpu_pc(p, (20, 0.5, 2.0), schur))
+        out.append(np.vstack([u0, u1]))
+    assert np.array_equal(out[0], out[1])
+    assert g2.info()["program_fallbacks"] == 1
