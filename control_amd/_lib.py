@@ -75,6 +75,7 @@ SIGNATURES = {
     "kkt_set_layout": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                  C.c_int, C.c_int, C.c_int]),
     "kkt_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "kkt_set_shard_families": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "kkt_shard_range": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                   C.POINTER(C.c_int)]),
     "kkt_add_block": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64,

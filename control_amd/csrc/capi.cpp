@@ -93,6 +93,9 @@ int kkt_shard_range(int m, int rank, int world, int *lo, int *hi) {
 }
 
 int kkt_set_shard(kkt_handle h, int rank, int world) { KKT_TRY(h, S.set_shard(rank, world)); }
+int kkt_set_shard_families(kkt_handle h, int rank, int world, int families) {
+    KKT_TRY(h, S.set_shard(rank, world, families));
+}
 
 int kkt_add_block(kkt_handle h, int q, int i, int j, int64_t nrows, int64_t ncols,
                   const int32_t *indptr, const int32_t *indices, const double *values,

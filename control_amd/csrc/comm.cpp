@@ -198,6 +198,39 @@ void comm_exchange_x_halos(System &S, const double *d_x) {
     S.comm->sendrecv(d_x + S.local_offset(1, 0), S.nx1, dn, S.d_halo_x1_hi, S.nx1, up, S.stream);
 }
 
+void comm_exchange_x_halos2(System &S, const double *d_x) {
+    if (!S.comm) fail(KKT_ERR_STATE, "time-sharded system without a transport");
+    const int up = S.rank + 1 < S.world ? S.rank + 1 : -1;
+    const int dn = S.rank > 0 ? S.rank - 1 : -1;
+    const int nl = S.hi - S.lo;
+    if (!S.halo2_agreed) {
+        // a rank sends what its neighbour's stencil reads: agree on the flags once
+        for (int v = 0; v < 2; ++v)
+            for (int f = 0; f < 2; ++f)
+                for (int side = 0; side < 2; ++side) {
+                    const double m = S.comm->max_host(S.halo2_used[v][f][side] ? 1.0 : 0.0, S.stream);
+                    S.halo2_used[v][f][side] = m > 0.5;
+                    if (S.halo2_used[v][f][side] && !S.d_halo2[v][f][side]) {
+                        const int64_t nxh = v == 0 ? S.nx0 : S.nx1;
+                        S.d_halo2[v][f][side] = dev_alloc<double>(nxh);
+                        HIPCHK(hipMemset(S.d_halo2[v][f][side], 0, nxh * 8));
+                    }
+                }
+        S.halo2_agreed = true;
+    }
+    for (int v = 0; v < 2; ++v) {
+        const int64_t nxh = v == 0 ? S.nx0 : S.nx1;
+        for (int f = 0; f < S.families; ++f) {
+            if (S.halo2_used[v][f][0])   // level lo-1 of my upper neighbour is my level hi-1
+                S.comm->sendrecv(d_x + S.local_offset(v, f * nl + nl - 1), nxh, up,
+                                 S.d_halo2[v][f][0], nxh, dn, S.stream);
+            if (S.halo2_used[v][f][1])   // level hi of my lower neighbour is my level lo
+                S.comm->sendrecv(d_x + S.local_offset(v, f * nl), nxh, dn, S.d_halo2[v][f][1], nxh,
+                                 up, S.stream);
+        }
+    }
+}
+
 void comm_exchange_row_halos(System &S, const double *d_y) {
     if (!S.comm) fail(KKT_ERR_STATE, "time-sharded system without a transport");
     const int up = S.rank + 1 < S.world ? S.rank + 1 : -1;

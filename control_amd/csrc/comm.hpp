@@ -30,6 +30,9 @@ void rccl_unique_id(void *out128);
 
 // x halos for the operator: x0 block hi-1 -> rank+1 (its halo_x0_lo), x1 block lo -> rank-1
 void comm_exchange_x_halos(System &S, const double *d_x);
+// two-family shards (outer incompressible system): per (variable, family) the level below and /
+// or above, as the stencil needs them (flags agreed over the ranks at the first call)
+void comm_exchange_x_halos2(System &S, const double *d_x);
 // raw-row halos for the CN transform: rho0 block lo -> rank-1 (halo_r0_hi),
 // rho1 block hi-1 -> rank+1 (halo_r1_lo)
 void comm_exchange_row_halos(System &S, const double *d_y);

@@ -112,16 +112,30 @@ StokesPC::StokesPC(System &outer, System &inner, System &commutator, const kkt_p
     : S_(outer), inner_(inner), comm_(commutator) {
     if (!outer.finalized || !inner.finalized || !commutator.finalized)
         fail(KKT_ERR_STATE, "kkt_set_pc_stokes needs three finalized systems");
-    if (outer.sharded || inner.sharded || commutator.sharded)
-        fail(KKT_ERR_STATE, "kkt_set_pc_stokes on time-sharded systems is not supported");
     if (outer.device != inner.device || outer.device != commutator.device)
         fail(KKT_ERR_ARG, "all three systems must live on one GPU");
-    n_ = d.n_p_blocks;
     cn_ = d.cn != 0;
     nv_ = d.nv;
     np_ = d.np;
-    if (n_ < 1 || outer.n0 != 2 * n_ || outer.n1 != 2 * n_ || outer.nx0 != nv_ || outer.nx1 != np_)
+    const int m_global = d.n_p_blocks;
+    if (m_global < 1 || outer.n0 != 2 * m_global || outer.n1 != 2 * m_global ||
+        outer.nx0 != nv_ || outer.nx1 != np_)
         fail(KKT_ERR_ARG, "outer system layout does not match the descriptor");
+    // Time sharding (BASELINE configs[4] names 8 GPUs): the outer system is sharded by
+    // levels of its two block families, the velocity and commutator systems by their levels --
+    // the same [lo, hi) on one rank.  Everything of this preconditioner except the nested solve
+    // and the commutator product is per pressure block, hence local; those two exchange their
+    // own halos.  n_ below is the LOCAL number of pressure blocks per family.
+    if (outer.sharded != inner.sharded || outer.sharded != commutator.sharded)
+        fail(KKT_ERR_STATE, "outer, velocity and commutator systems must be sharded alike");
+    if (outer.sharded) {
+        if (cn_) fail(KKT_ERR_STATE, "time-sharded StokesPC: Crank-Nicolson branch not supported");
+        if (outer.families != 2 || inner.families != 1 || commutator.families != 1 ||
+            outer.lo != inner.lo || outer.hi != inner.hi || outer.lo != commutator.lo ||
+            outer.hi != commutator.hi)
+            fail(KKT_ERR_STATE, "shards of the three systems do not match");
+    }
+    n_ = outer.sharded ? outer.hi - outer.lo : m_global;
     if (inner.n_local != 2 * (int64_t)n_ * nv_)
         fail(KKT_ERR_ARG, "inner (velocity) system has the wrong size");
     if (commutator.n_local != 2 * (int64_t)n_ * np_)

@@ -69,6 +69,9 @@ System::~System() {
     F(d_halo_x1_hi);
     F(d_halo_r0_hi);
     F(d_halo_r1_lo);
+    for (auto &a : d_halo2)
+        for (auto &b : a)
+            for (double *q : b) F(q);
     F(d_V);
     F(d_Z);
     F(d_w);
@@ -106,19 +109,25 @@ void System::set_layout(int n_blocks_00, int n_blocks_11, int64_t nx0_, int64_t 
     if (e && (e[0] == '1' || e[0] == '2')) sell_R = e[0] - '0';
 }
 
-void System::set_shard(int rank_, int world_) {
+void System::set_shard(int rank_, int world_, int families_) {
     if (!layout_set || finalized || !blocks.empty())
         fail(KKT_ERR_STATE, "kkt_set_shard must follow kkt_set_layout and precede blocks");
     if (world_ < 1 || rank_ < 0 || rank_ >= world_) fail(KKT_ERR_ARG, "bad rank/world");
+    if (families_ != 1 && families_ != 2) fail(KKT_ERR_ARG, "1 or 2 block families");
     if (world_ == 1) return;
     if (n0 != n1) fail(KKT_ERR_ARG, "time sharding needs n_blocks_00 == n_blocks_11");
     if (sub00 >= 0) fail(KKT_ERR_ARG, "time sharding with sub-block splits is not supported");
-    if (world_ > n0) fail(KKT_ERR_ARG, "more ranks than time-block rows");
+    if (families_ == 2 && CN)
+        fail(KKT_ERR_ARG, "time sharding of a two-family Crank-Nicolson system is not supported");
+    if (n0 % families_ != 0) fail(KKT_ERR_ARG, "block count is not a multiple of the families");
+    families = families_;
+    mf = n0 / families;
+    if (world_ > mf) fail(KKT_ERR_ARG, "more ranks than time levels");
     rank = rank_;
     world = world_;
-    kkt_shard_range(n0, rank, world, &lo, &hi);
+    kkt_shard_range(mf, rank, world, &lo, &hi);
     sharded = true;
-    n0_loc = n1_loc = hi - lo;
+    n0_loc = n1_loc = families * (hi - lo);
 }
 
 // Fingerprint of an index array (a filter in front of the memcmp in find_or_add_pattern).
@@ -298,15 +307,23 @@ void System::add_block(int q, int i, int j, int64_t nrows, int64_t ncols,
     if (i < 0 || i >= nr || j < 0 || j >= nc) fail(KKT_ERR_ARG, "block index out of range");
     if (nrows != er || ncols != ec) fail(KKT_ERR_ARG, "block shape does not match the layout");
     if (sharded) {
-        if (i < lo || i >= hi) fail(KKT_ERR_ARG, "block row not owned by this rank");
-        if (j < lo - 1 || j > hi) fail(KKT_ERR_ARG, "time sharding needs |i - j| <= 1 blocks");
-        // one halo per column variable is exchanged: x0 of block lo-1 and x1 of block hi
-        // (comm_exchange_x_halos) -- the couplings of the BE / CN stencils, control.py:2909-2953
+        if (!owns(i)) fail(KKT_ERR_ARG, "block row not owned by this rank");
+        const int lj = level_of(j);
+        if (lj < lo - 1 || lj > hi) fail(KKT_ERR_ARG, "time sharding needs |i - j| <= 1 blocks");
         const bool col0 = q == KKT_Q00 || q == KKT_Q10;
-        if (col0 && j == hi)
-            fail(KKT_ERR_ARG, "time sharding: a block of column variable 0 may reach block lo-1, not hi");
-        if (!col0 && j == lo - 1)
-            fail(KKT_ERR_ARG, "time sharding: a block of column variable 1 may reach block hi, not lo-1");
+        if (families == 1) {
+            // one halo per column variable is exchanged: x0 of block lo-1 and x1 of block hi
+            // (comm_exchange_x_halos) -- the couplings of the BE / CN stencils, control.py:2909-2953
+            if (col0 && j == hi)
+                fail(KKT_ERR_ARG, "time sharding: a block of column variable 0 may reach block lo-1, not hi");
+            if (!col0 && j == lo - 1)
+                fail(KKT_ERR_ARG, "time sharding: a block of column variable 1 may reach block hi, not lo-1");
+        } else {
+            // two families: whatever the stencil couples -- recorded per (variable, family, side)
+            const int li = level_of(i);
+            if (lj == li - 1) halo2_used[col0 ? 0 : 1][family_of(j)][0] = true;
+            if (lj == li + 1) halo2_used[col0 ? 0 : 1][family_of(j)][1] = true;
+        }
     }
     auto key = std::make_tuple(q, i, j);
     if (blocks.count(key)) fail(KKT_ERR_ARG, "block added twice");
@@ -513,14 +530,21 @@ void System::finalize() {
                         op.t[nt].vals = values[b->va].d_vals;
                         block_term[std::make_tuple(b->q, b->i, b->j)] =
                             std::make_tuple((int)w, waves.size() > w ? (int)waves[w].size() : 0, nt);
-                        const int jl = sharded ? b->j - lo : b->j;
-                        const int ncl = col0 ? n0_loc : n1_loc;
-                        if (jl >= 0 && jl < ncl) {
-                            op.t[nt].x = vref(1, local_offset(col0 ? 0 : 1, jl));
-                        } else if (jl < 0) {
-                            op.t[nt].x = vref(3, 0);   // halo below (block lo-1)
+                        const int lj = level_of(b->j);
+                        if (!sharded || (lj >= lo && lj < hi)) {
+                            op.t[nt].x = vref(1, local_offset(col0 ? 0 : 1, local_of(b->j)));
+                        } else if (families == 1) {
+                            op.t[nt].x = lj < lo ? vref(3, 0)    // halo below (block lo-1)
+                                                 : vref(4, 0);   // halo above (block hi)
                         } else {
-                            op.t[nt].x = vref(4, 0);   // halo above (block hi)
+                            // two families: fixed halo buffers, addressed absolutely
+                            const int v = col0 ? 0 : 1, f = family_of(b->j), side = lj < lo ? 0 : 1;
+                            if (!d_halo2[v][f][side]) {
+                                const int64_t nxh = v == 0 ? nx0 : nx1;
+                                d_halo2[v][f][side] = dev_alloc<double>(nxh);
+                                HIPCHK(hipMemset(d_halo2[v][f][side], 0, nxh * 8));
+                            }
+                            op.t[nt].x = VRef{(int64_t)(uintptr_t)d_halo2[v][f][side], 0, 0};
                         }
                         ++nt;
                         ++t0;
@@ -766,7 +790,12 @@ void System::apply(const double *d_x, double *d_y) {
                              d_sums);
         xin = d_xc;
     }
-    if (sharded) comm_exchange_x_halos(*this, xin);
+    if (sharded) {
+        if (families == 1)
+            comm_exchange_x_halos(*this, xin);
+        else
+            comm_exchange_x_halos2(*this, xin);
+    }
     Bases B{{xin, d_y, d_halo_x0_lo, d_halo_x1_hi}};
     for (const RowLaunch &L : apply_launches) {
         if (L.ngroups > 0 &&

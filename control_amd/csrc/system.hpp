@@ -135,8 +135,22 @@ struct System {
     int sub00 = -1, sub11 = -1;
     // time shard
     int rank = 0, world = 1;
-    int lo = 0, hi = 0;            // owned block rows of both variables (sharded only)
+    int lo = 0, hi = 0;            // owned time levels of both variables (sharded only)
     bool sharded = false;
+    // Block families: the flat blocks of a variable are `families` runs of mf = n / families time
+    // levels (1: heat-type systems; 2: the outer incompressible system, velocity blocks (v, zeta)
+    // and pressure blocks (mu, p), control.py:3654-3673).  A rank owns levels [lo, hi) of every
+    // family; local flat block f * (hi - lo) + (level - lo).
+    int families = 1, mf = 0;
+    int level_of(int k) const { return sharded ? k % mf : k; }
+    int family_of(int k) const { return sharded ? k / mf : 0; }
+    bool owns(int k) const { return !sharded || (level_of(k) >= lo && level_of(k) < hi); }
+    int local_of(int k) const { return sharded ? family_of(k) * (hi - lo) + level_of(k) - lo : k; }
+    // halo blocks of a 2-family shard: [variable][family][0: level lo-1, 1: level hi]
+    double *d_halo2[2][2][2] = {{{nullptr, nullptr}, {nullptr, nullptr}},
+                                {{nullptr, nullptr}, {nullptr, nullptr}}};
+    bool halo2_used[2][2][2] = {{{false, false}, {false, false}}, {{false, false}, {false, false}}};
+    bool halo2_agreed = false;     // usage flags made consistent over the ranks (first apply)
     int n0_loc = 1, n1_loc = 1;    // local block counts
     int64_t n_local = 0;           // local vector length
     int64_t vec_stride = 0;        // padded allocation length of internal vectors
@@ -205,7 +219,7 @@ struct System {
     // -- definition
     void set_layout(int n_blocks_00, int n_blocks_11, int64_t nx0_, int64_t nx1_, int CN_,
                     int s00, int s11);
-    void set_shard(int rank_, int world_);
+    void set_shard(int rank_, int world_, int families_ = 1);
     void add_block(int q, int i, int j, int64_t nrows, int64_t ncols, const int32_t *indptr,
                    const int32_t *indices, const double *vals, int64_t share_id);
     void update_block_values(int q, int i, int j, const double *vals);
@@ -223,7 +237,12 @@ struct System {
     int64_t local_offset(int var, int local_i) const {
         return var == 0 ? (int64_t)local_i * nx0 : (int64_t)n0_loc * nx0 + (int64_t)local_i * nx1;
     }
-    int global_row(int var, int local_i) const { return sharded ? lo + local_i : local_i; }
+    int global_row(int var, int local_i) const {
+        (void)var;
+        if (!sharded) return local_i;
+        const int nl = hi - lo;
+        return (local_i / nl) * mf + lo + local_i % nl;
+    }
     double *new_vec();   // internal vector of vec_stride doubles (zeroed)
 
     // -- operations on device vectors of n_local doubles

@@ -189,7 +189,7 @@ class MultiBlockSystem:
                  n_blocks_00=1, n_blocks_11=1, sub_n_blocks_00_0=None,
                  sub_n_blocks_11_0=None, nullspace_0=None, nullspace_1=None,
                  form_compiler_parameters=None, CN=False, device=0, comm=None, options=None,
-                 share_values=True):
+                 share_values=True, shard_families=1):
         if nullspace_0 is None:
             nullspace_0 = tuple(NoneNullspace() for _ in range(n_blocks_00))
         if nullspace_1 is None:
@@ -220,15 +220,21 @@ class MultiBlockSystem:
             -1 if sub_n_blocks_00_0 is None else int(sub_n_blocks_00_0),
             -1 if sub_n_blocks_11_0 is None else int(sub_n_blocks_11_0)))
         self._lo, self._hi = 0, n_blocks_00
+        # time levels per block family (shard_families = 2: the outer incompressible system,
+        # whose flat blocks are (v, zeta) and (mu, p) runs of time levels)
+        self._mf = n_blocks_00 // int(shard_families)
         if comm is not None and comm.world > 1:
-            self._ck(self._lib.kkt_set_shard(self._h, comm.rank, comm.world))
+            if shard_families == 1:
+                self._ck(self._lib.kkt_set_shard(self._h, comm.rank, comm.world))
+            else:
+                self._ck(self._lib.kkt_set_shard_families(self._h, comm.rank, comm.world,
+                                                          int(shard_families)))
             lo, hi = C.c_int(), C.c_int()
-            self._lib.kkt_shard_range(n_blocks_00, comm.rank, comm.world,
-                                      C.byref(lo), C.byref(hi))
+            self._lib.kkt_shard_range(self._mf, comm.rank, comm.world, C.byref(lo), C.byref(hi))
             self._lo, self._hi = lo.value, hi.value
         self._sharded = comm is not None and comm.world > 1
-        self._n0_loc = self._hi - self._lo if self._sharded else n_blocks_00
-        self._n1_loc = self._hi - self._lo if self._sharded else n_blocks_11
+        self._n0_loc = shard_families * (self._hi - self._lo) if self._sharded else n_blocks_00
+        self._n1_loc = shard_families * (self._hi - self._lo) if self._sharded else n_blocks_11
 
         share_ids = {}
         self._structure = {}     # (quadrant, i, j) -> [nnz, hash of the index array or None, the array]
@@ -236,7 +242,7 @@ class MultiBlockSystem:
             for (i, j), A in blk.items():                      # dict order = apply order
                 if A is None:
                     continue
-                if self._sharded and not (self._lo <= i < self._hi):
+                if self._sharded and not (self._lo <= i % self._mf < self._hi):
                     continue
                 indptr, indices, data = _as_csr(A)
                 nrows = len(indptr) - 1

@@ -62,7 +62,7 @@ def stokes_problem(n=4, n_t=4, beta=1.0e-2, T=2.0, CN=False, share=True):
     return dict(th=th, tau=tau, beta=beta, n_t=n_t, CN=CN, m=bl["m"], blocks=bl)
 
 
-def stokes_gpu(p, specs=STOKES_SPECS, options=None):
+def stokes_gpu(p, specs=STOKES_SPECS, options=None, comm=None):
     """Outer system, velocity KKT system and pressure commutator on the GPU + the StokesPC."""
     from .multiblock import (ChebSpec, ConstantNullspace, DirichletBCNullspace,
                              MultiBlockSystem, SchurPC, StokesPC)
@@ -72,17 +72,19 @@ def stokes_gpu(p, specs=STOKES_SPECS, options=None):
     outer = MultiBlockSystem(th.n_v, th.n_p, *bl["outer"], n_blocks_00=2 * m,
                              n_blocks_11=2 * m, nullspace_0=(nsv,) * (2 * m),
                              nullspace_1=tuple(ConstantNullspace() for _ in range(2 * m)),
-                             CN=CN, options=options, **kw)
+                             CN=CN, options=options, comm=comm, shard_families=2, **kw)
     inner = MultiBlockSystem(th.n_v, th.n_v, *bl["inner"], n_blocks_00=m, n_blocks_11=m,
                              nullspace_0=(nsv,) * m, nullspace_1=(nsv,) * m, CN=CN,
-                             options=options)
+                             options=options, comm=comm)
     # the commutator product is a plain block product (control.py:4625-4665): no transforms
-    comm = MultiBlockSystem(th.n_p, th.n_p, *bl["commutator"], n_blocks_00=m, n_blocks_11=m,
-                            options=options)
+    # (time-sharded with `comm`: the outer system by levels of its two block families, the
+    # velocity and commutator systems by their levels -- the same [lo, hi) on a rank)
+    commutator = MultiBlockSystem(th.n_p, th.n_p, *bl["commutator"], n_blocks_00=m,
+                                  n_blocks_11=m, options=options, comm=comm)
     inner_pc = SchurPC(kind="CN" if CN else "BE", M=th.M_v, beta=p["beta"],
                        bc_nodes=th.boundary_v, mass=ChebSpec(*specs["mass"]),
                        schur=ChebSpec(*specs["schur"]), n_t=p["n_t"], tau=p["tau"])
-    gpc = StokesPC(inner=inner, inner_pc=inner_pc, commutator=comm, B=th.B, K_p=th.K_p,
+    gpc = StokesPC(inner=inner, inner_pc=inner_pc, commutator=commutator, B=th.B, K_p=th.K_p,
                    M_p=th.M_p, kp=ChebSpec(*specs["kp"]), mp=ChebSpec(*specs["mp"]),
                    n_p_blocks=m, b_scale=p["tau"], post_scale=1.0 / p["tau"]**2, cn=CN)
     return outer, gpc

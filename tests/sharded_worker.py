@@ -49,3 +49,46 @@ def run_rank(rank, world, conns, CN, ksp, out_q):
     except Exception as e:   # report instead of hanging the other ranks' pipes
         import traceback
         out_q.put((rank, "error", traceback.format_exc() + repr(e)))
+
+
+def run_rank_stokes(rank, world, conns, out_q):
+    """Time-sharded instationary Stokes control (BE): the outer system is sharded by levels of
+    its two block families, the nested velocity solve and the commutator product by theirs."""
+    try:
+        import common
+        from control_amd.dist import CallbackComm, PipeTransport, shard_range
+        p = common.stokes_problem(n=4, n_t=6, CN=False)
+        th, m = p["th"], p["m"]
+        lo, hi = shard_range(m, rank, world)
+        nl = hi - lo
+        tr = PipeTransport(rank, world, conns)
+        comm = CallbackComm(rank, world, tr.allreduce, tr.sendrecv)
+        osys, opc = common.stokes_oracle(p)
+        outer, gpc = common.stokes_gpu(p, comm=comm)
+
+        def shard(v):   # global flat -> [v_lo.., zeta_lo.. | mu_lo.., p_lo..]
+            v0, v1 = osys.split(np.asarray(v))
+            return np.concatenate([v0[lo:hi].ravel(), v0[m + lo:m + hi].ravel(),
+                                   v1[lo:hi].ravel(), v1[m + lo:m + hi].ravel()])
+
+        x = common.rng_vector(osys.N)
+        e_op = common.rel_err(outer.mult(shard(x)), shard(osys.mult(x)))
+        e_pc = common.rel_err(outer.pc_apply(shard(x), gpc), shard(osys.pc_apply(opc, x)))
+        rng = np.random.default_rng(common.SEED)
+        x0 = rng.standard_normal((2 * m, th.n_v))
+        x0[:, th.boundary_v] = 0.0
+        x1 = rng.standard_normal((2 * m, th.n_p))
+        x1 -= x1.mean(axis=1, keepdims=True)
+        b0, b1 = osys.split(osys.mult(osys.join(x0, x1)))
+        pick = list(range(lo, hi)) + list(range(m + lo, m + hi))
+        u0, u1 = np.zeros((2 * nl, th.n_v)), np.zeros((2 * nl, th.n_p))
+        res = outer.solve(u0, u1, b0[pick].copy(), b1[pick].copy(), pc_fn=gpc, solver_parameters={
+            "linear_solver": "fgmres", "maximum_iterations": 200, "relative_tolerance": 1.0e-10,
+            "absolute_tolerance": 1.0e-30, "monitor_convergence": False})
+        e_u0 = float(np.abs(u0 - x0[pick]).max())
+        e_u1 = float(np.abs(u1 - u1.mean(axis=1, keepdims=True) - x1[pick]).max())
+        out_q.put((rank, "ok", dict(e_op=e_op, e_pc=e_pc, e_u0=e_u0, e_u1=e_u1, reason=res.reason,
+                                    its=res.its, hist=np.asarray(res.history).tolist())))
+    except Exception as e:
+        import traceback
+        out_q.put((rank, "error", traceback.format_exc() + repr(e)))
