@@ -81,6 +81,9 @@ System::~System() {
     F(d_hcol);
     F(d_coef);
     if (h_pinned) (void)hipHostFree(h_pinned);
+    if (ev_x_ready) (void)hipEventDestroy(ev_x_ready);
+    if (ev_halo_ready) (void)hipEventDestroy(ev_halo_ready);
+    if (comm_stream) (void)hipStreamDestroy(comm_stream);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -463,18 +466,24 @@ void System::finalize() {
     fused_row_masks = !CN;
 
     // ---- row plan: one RowOp per (row, run of same-pattern terms), chained by accumulation
-    std::vector<std::vector<RowOp>> waves;   // waves[w] = ops of launch w
-    std::vector<int> wave_slices, wave_R;
-    auto put = [&](size_t w, const RowOp &op, int nslices, int R) {
-        if (waves.size() <= w) {
-            waves.resize(w + 1);
-            wave_slices.resize(w + 1, 0);
-            wave_R.resize(w + 1, R);
+    // Time-sharded handles keep the block rows that read a neighbour's level (through a halo
+    // block) in launches of their own, behind the rows that do not: the halo exchange then runs
+    // on the transport's stream while the interior rows compute.
+    struct RowPlan {
+        std::vector<std::vector<RowOp>> waves;   // waves[w] = ops of launch w
+        std::vector<int> slices, R;
+    } plan_int, plan_halo;
+    std::map<std::tuple<int, int, int>, bool> term_in_halo_plan;
+    auto put = [&](RowPlan &pl, size_t w, const RowOp &op, int nslices, int R) {
+        if (pl.waves.size() <= w) {
+            pl.waves.resize(w + 1);
+            pl.slices.resize(w + 1, 0);
+            pl.R.resize(w + 1, R);
         }
-        if (!waves[w].empty() && wave_R[w] != R) fail(KKT_ERR_STATE, "mixed SELL R in a launch");
-        wave_R[w] = R;
-        waves[w].push_back(op);
-        wave_slices[w] = std::max(wave_slices[w], nslices);
+        if (!pl.waves[w].empty() && pl.R[w] != R) fail(KKT_ERR_STATE, "mixed SELL R in a launch");
+        pl.R[w] = R;
+        pl.waves[w].push_back(op);
+        pl.slices[w] = std::max(pl.slices[w], nslices);
     };
     for (int var = 0; var < 2; ++var) {
         const int nloc = var == 0 ? n0_loc : n1_loc;
@@ -492,6 +501,12 @@ void System::finalize() {
                           [](const Block *a, const Block *b) { return a->order < b->order; });
                 terms.insert(terms.end(), row.begin(), row.end());
             }
+            bool row_halo = false;
+            for (const Block *b : terms) {
+                const int lj = level_of(b->j);
+                row_halo = row_halo || (sharded && (lj < lo || lj >= hi));
+            }
+            RowPlan &pl = row_halo ? plan_halo : plan_int;
             const int64_t yoff = local_offset(var, il);
             const int flat_g = var == 0 ? gi : n0 + gi;
             const NullspaceSpec &rns = nullspaces[flat_g];
@@ -529,7 +544,8 @@ void System::finalize() {
                         const bool col0 = b->q == KKT_Q00 || b->q == KKT_Q10;
                         op.t[nt].vals = values[b->va].d_vals;
                         block_term[std::make_tuple(b->q, b->i, b->j)] =
-                            std::make_tuple((int)w, waves.size() > w ? (int)waves[w].size() : 0, nt);
+                            std::make_tuple((int)w, pl.waves.size() > w ? (int)pl.waves[w].size() : 0, nt);
+                        term_in_halo_plan[std::make_tuple(b->q, b->i, b->j)] = row_halo;
                         const int lj = level_of(b->j);
                         if (!sharded || (lj >= lo && lj < hi)) {
                             op.t[nt].x = vref(1, local_offset(col0 ? 0 : 1, local_of(b->j)));
@@ -569,12 +585,22 @@ void System::finalize() {
                     op.mx = vref(1, yoff);
                     op.malpha = rns.alpha;
                 }
-                put(w, op, nslices, R);
+                put(pl, w, op, nslices, R);
                 wrote = true;
                 ++w;
             }
         }
     }
+    std::vector<std::vector<RowOp>> waves = plan_int.waves;
+    std::vector<int> wave_slices = plan_int.slices, wave_R = plan_int.R;
+    first_halo_launch = (int)waves.size();
+    for (size_t w = 0; w < plan_halo.waves.size(); ++w) {
+        waves.push_back(plan_halo.waves[w]);
+        wave_slices.push_back(plan_halo.slices[w]);
+        wave_R.push_back(plan_halo.R[w]);
+    }
+    for (auto &kv : block_term)
+        if (term_in_halo_plan[kv.first]) std::get<0>(kv.second) += first_halo_launch;
     for (size_t w = 0; w < waves.size(); ++w) {
         RowLaunch L;
         L.nops = (int)waves[w].size();
@@ -791,19 +817,42 @@ void System::apply(const double *d_x, double *d_y) {
         xin = d_xc;
     }
     if (sharded) {
-        if (families == 1)
-            comm_exchange_x_halos(*this, xin);
-        else
-            comm_exchange_x_halos2(*this, xin);
+        // the exchange runs on the transport's stream, behind whatever produced x ...
+        if (!comm_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&ev_x_ready, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&ev_halo_ready, hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(ev_x_ready, stream));
+        HIPCHK(hipStreamWaitEvent(comm_stream, ev_x_ready, 0));
     }
     Bases B{{xin, d_y, d_halo_x0_lo, d_halo_x1_hi}};
-    for (const RowLaunch &L : apply_launches) {
+    auto launch = [&](const RowLaunch &L) {
         if (L.ngroups > 0 &&
             launch_rowops_grouped(stream, L.d_ops, L.d_groups, L.ngroups, L.max_slices, L.R,
                                   L.uniform_w, B))
-            continue;
+            return;
         launch_rowops(stream, L.d_ops, L.nops, L.max_slices, L.R, B, 0, L.uniform_w);
+    };
+    // ... while the block rows that need no neighbour's level are already queued
+    for (int w = 0; w < first_halo_launch; ++w) launch(apply_launches[w]);
+    if (sharded) {
+        hipStream_t compute = stream;
+        stream = comm_stream;          // the exchange helpers work on S.stream
+        try {
+            if (families == 1)
+                comm_exchange_x_halos(*this, xin);
+            else
+                comm_exchange_x_halos2(*this, xin);
+        } catch (...) {
+            stream = compute;
+            throw;
+        }
+        stream = compute;
+        HIPCHK(hipEventRecord(ev_halo_ready, comm_stream));
+        HIPCHK(hipStreamWaitEvent(stream, ev_halo_ready, 0));
     }
+    for (size_t w = (size_t)first_halo_launch; w < apply_launches.size(); ++w) launch(apply_launches[w]);
     if (CN) {
         if (sharded) comm_exchange_row_halos(*this, d_y);
         for (const TimeGroup &g : time_groups) {

@@ -167,6 +167,9 @@ struct System {
 
     // apply plan
     std::vector<RowLaunch> apply_launches;
+    int first_halo_launch = 0;    // launches [first_halo_launch, end) hold the rows that read a halo
+    hipStream_t comm_stream = nullptr;              // halo exchange, overlapped with interior rows
+    hipEvent_t ev_x_ready = nullptr, ev_halo_ready = nullptr;
     std::vector<std::vector<RowOp>> h_apply_ops;   // host copies (value pointers are re-pointed
                                                    // when an update un-shares a value array)
     std::map<std::tuple<int, int, int>, std::tuple<int, int, int>> block_term;   // -> launch, op, term

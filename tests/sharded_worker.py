@@ -26,7 +26,12 @@ def run_rank(rank, world, conns, CN, ksp, out_q):
             return np.concatenate([V[lo:hi].ravel(), V[m + lo:m + hi].ravel()])
 
         x = common.rng_vector(osys.N)
-        e_op = common.rel_err(gsys.mult(shard(x)), shard(osys.mult(x)))
+        y_shard = gsys.mult(shard(x))
+        e_op = common.rel_err(y_shard, shard(osys.mult(x)))
+        # interior block rows run while the halo travels; the rows that read it run after: the
+        # same RowOps as on a single GPU, so the shard equals the single-rank result bit for bit
+        single = common.gpu_system(p)
+        op_bitwise = bool(np.array_equal(y_shard, shard(single.mult(x))))
         e_pc = common.rel_err(gsys.pc_apply(shard(x), gpc), shard(osys.pc_apply(opc, x)))
         X = p["sd"].coords
         xs = np.stack([np.sin(np.pi * X[:, 0]) * np.sin(np.pi * X[:, 1]) * (1 + 0.1 * k)
@@ -45,7 +50,7 @@ def run_rank(rank, world, conns, CN, ksp, out_q):
         n = min(len(ho), len(hg))
         e_h = float(np.max(np.abs(hg[:n] - ho[:n]) / ho[:n]))
         out_q.put((rank, "ok", dict(e_op=e_op, e_pc=e_pc, e_u=e_u, e_h=e_h, its_g=rg.its,
-                                    its_o=ro.its, hist=hg.tolist())))
+                                    its_o=ro.its, hist=hg.tolist(), op_bitwise=op_bitwise)))
     except Exception as e:   # report instead of hanging the other ranks' pipes
         import traceback
         out_q.put((rank, "error", traceback.format_exc() + repr(e)))

@@ -54,6 +54,7 @@ def test_sharded_matches_oracle(world, CN):
     for r in range(world):
         d = res[r]
         assert d["e_op"] < 1e-13, d
+        assert d["op_bitwise"], d
         assert d["e_pc"] < 1e-10, d
         assert abs(d["its_g"] - d["its_o"]) <= (0 if CN else 1), d
         assert d["e_u"] < (1e-6 if CN else 1e-5), d
