@@ -52,8 +52,8 @@ def measured_sweep_traffic(workload, preconditioner, phases_per_launch):
     (profiles/*/traffic_pc_row_program_g.json) for this workload and preconditioner."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*",
-                                           "traffic_pc_row_program_g.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic_pc_row_program_g.json"))
+                    + glob.glob(os.path.join(ROOT, "profiles", "*", "traffic_pc_tile_sweep.json"))):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):

@@ -287,3 +287,85 @@ def test_sweep_program_timeout_falls_back_to_plain_launches():
         out.append(np.vstack([u0, u1]))
     assert np.array_equal(out[0], out[1])
     assert g2.info()["program_fallbacks"] == 1
+
+
+def test_zero_right_hand_side_with_nonzero_guess_converges_to_zero():
+    """KSPConvergedDefault's special case: with b = 0 the norm of the first residual takes the
+    place of the (zero) right-hand-side norm, so a non-zero initial guess is iterated towards
+    u = 0 instead of being reported as diverged at the first test (gmres, fgmres and the oracle
+    alike).  FGMRES monitors the true residual: its iterate really reaches 0; left-preconditioned
+    GMRES stops on the preconditioned norm (the BE preconditioner scales the last level by
+    1 / epsilon), so only the stopping behaviour is compared there."""
+    p = common.heat_problem(n=10, n_t=6, beta=1e-2)
+    m, nx = p["m"], p["sd"].n_dofs
+    mass, schur = (20, 0.5, 2.0), (12, 0.08, 2.1)
+    for ksp in ("gmres", "fgmres"):
+        sp_ = {"linear_solver": ksp, "gmres_restart": 10, "maximum_iterations": 100,
+               "relative_tolerance": 1e-8, "absolute_tolerance": 0.0, "monitor_convergence": False}
+        outs = []
+        for sysm, pc in ((common.gpu_system(p), common.gpu_pc(p, mass, schur)),
+                         (common.oracle_system(p), common.oracle_pc(p, mass, schur))):
+            u0 = common.rng_vector(m * nx, 3).reshape(m, nx)
+            u1 = common.rng_vector(m * nx, 4).reshape(m, nx)
+            r = sysm.solve(u0, u1, np.zeros((m, nx)), np.zeros((m, nx)), solver_parameters=sp_,
+                           pc_fn=pc)
+            assert r.reason > 0
+            assert r.history[-1] <= 1e-8 * r.history[0]
+            if ksp == "fgmres":
+                assert max(np.abs(u0).max(), np.abs(u1).max()) < 1e-5
+            outs.append(r.its)
+        assert abs(outs[0] - outs[1]) <= 1
+
+
+def test_updating_one_of_two_shared_blocks_leaves_the_other_alone():
+    """Blocks given as one object share a value array on the device.  The reference assembles
+    every block on its own, so new values for one of them must not reach the other (copy on
+    write); re-sending identical values changes nothing."""
+    nx = 150
+    A = ragged(nx, nx, 11) + sp.identity(nx, format="csr")
+    A.sort_indices()
+    B = A.copy()
+    B.data = B.data * 1.5 + 0.25
+    b00 = {(0, 0): A, (0, 1): None, (1, 0): None, (1, 1): A}
+    none = {(i, j): None for i in range(2) for j in range(2)}
+    g, o = pair(nx, nx, (b00, dict(none), dict(none), dict(none)), 2, 2,
+                (NoneNullspace(), NoneNullspace()), (NoneNullspace(), NoneNullspace()),
+                (ko.NoneNullspace(), ko.NoneNullspace()), (ko.NoneNullspace(), ko.NoneNullspace()))
+    x = common.rng_vector(o.N, 5)
+    assert g.info()["n_value_arrays"] == 1
+    g.update_block_values(0, 0, 0, A)                      # identical values: still shared
+    assert g.info()["n_value_arrays"] == 1
+    g.update_block_values(0, 0, 0, B)                      # new values: block (0, 0) only
+    assert g.info()["n_value_arrays"] == 2
+    o2 = ko.OracleSystem(nx, nx, {(0, 0): B, (0, 1): None, (1, 0): None, (1, 1): A}, dict(none),
+                         dict(none), dict(none), n_blocks_00=2, n_blocks_11=2)
+    assert common.rel_err(g.mult(x), o2.mult(x)) < 1e-13
+
+
+def test_sharded_handle_rejects_blocks_whose_halo_is_not_exchanged():
+    """One halo per column variable travels on a heat-type shard (x0 of level lo-1, x1 of level
+    hi): a block that would read the other side must be refused, not multiplied with the
+    wrong vector."""
+    import ctypes as C
+    from control_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.kkt_create(C.byref(h), 0) == 0
+    try:
+        nx = 40
+        A = sp.identity(nx, format="csr")
+        ip, ix, va = (np.ascontiguousarray(A.indptr, dtype=np.int32),
+                      np.ascontiguousarray(A.indices, dtype=np.int32),
+                      np.ascontiguousarray(A.data, dtype=np.float64))
+        assert lib.kkt_set_layout(h, 6, 6, nx, nx, 0, -1, -1) == 0
+        assert lib.kkt_set_shard(h, 1, 3) == 0             # owns levels [2, 4)
+        add = lambda q, i, j: lib.kkt_add_block(                                  # noqa: E731
+            h, q, i, j, nx, nx, ip.ctypes.data_as(_lib.c_i32p), ix.ctypes.data_as(_lib.c_i32p),
+            va.ctypes.data_as(_lib.c_f64p), -1)
+        assert add(2, 2, 1) == 0                           # Q10: x0 of level lo - 1: exchanged
+        assert add(1, 3, 4) == 0                           # Q01: x1 of level hi: exchanged
+        assert add(2, 3, 4) == -1                          # Q10 reading x0 of level hi
+        assert b"lo-1, not hi" in lib.kkt_last_error(h)
+        assert add(1, 2, 1) == -1                          # Q01 reading x1 of level lo - 1
+    finally:
+        lib.kkt_destroy(h)
