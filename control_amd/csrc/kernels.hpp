@@ -127,8 +127,15 @@ struct TileArgs {
     int32_t poll_delay;                       // s_sleep units between publishing and the first poll
     int32_t debug_drop;                       // test hook: tile 0 skips publishing hand-off number
                                               // debug_drop (> 0), so its neighbours time out
+    uint32_t epoch0;                          // hand-offs of this launch carry tags epoch0 + 1, ...
+    int32_t clear;                            // zero the granule buffers before the launch (the
+                                              // first tile launch of a replayed sequence)
+    int32_t fused_update;                     // 0: kernel variant without the level update
 };
 bool tile_sweep_available(int W, int rpt, int threads);
+// whether the variant for this shape computes the level update b -= U u_prev itself (narrow
+// rows); wide rows (3-D P1) have no registers for it: the update stays a launch of its own
+bool tile_sweep_fuses_update(int W);
 size_t tile_sweep_lds_bytes(int nk_pad, int its);
 // workgroups of `threads` that are certainly co-resident (one per CU)
 int tile_sweep_max_tiles(int W, int rpt, int threads, size_t lds_bytes);

@@ -291,14 +291,22 @@ bool SchurPC::prepare_tiles() {
     // workgroup size: 1 024 threads (one row slot per thread, 128 registers) or 512 (up to three
     // row slots, 256 registers) -- whichever the model prefers, unless the caller chose
     int threads = 0;
+    // Dirichlet rows belong to no tile (their iterates are exactly zero)
+    std::vector<uint8_t> hmask;
+    if (!bc_idx_.empty()) {
+        hmask.assign(P.nrows, 0);
+        for (int32_t k : bc_idx_) hmask[k] = 1;
+    }
+    const uint8_t *hm = hmask.empty() ? nullptr : hmask.data();
     if (tw) {
         threads = 64 * std::max(1, std::min(16, std::atoi(tw)));
-        if (!build_tile_plan(P, ntiles, depth, threads, threads > 512 ? 1 : 3, tile_plan_)) return false;
+        if (!build_tile_plan(P, ntiles, depth, threads, threads > 512 ? 1 : 3, tile_plan_, hm))
+            return false;
     } else {
         TilePlan big;
-        const bool ok_big = build_tile_plan(P, ntiles, depth, 1024, 1, big) &&
+        const bool ok_big = build_tile_plan(P, ntiles, depth, 1024, 1, big, hm) &&
                             tile_sweep_available(big.W, big.rpt, 1024);
-        const bool ok_small = build_tile_plan(P, ntiles, depth, 512, 3, tile_plan_) &&
+        const bool ok_small = build_tile_plan(P, ntiles, depth, 512, 3, tile_plan_, hm) &&
                               tile_sweep_available(tile_plan_.W, tile_plan_.rpt, 512);
         if (!ok_big && !ok_small) return false;
         if (ok_big && (!ok_small || big.model_us <= tile_plan_.model_us)) tile_plan_ = big;
@@ -369,14 +377,44 @@ bool SchurPC::fuse_tile_run(size_t k, size_t e, std::vector<PcStep> &out) {
         L.coef = d_coef;
         levels.push_back(L);
     }
-    for (size_t q = k; q < e; ++q) (void)hipFree(steps_[q].rows.d_ops);
-    PcStep s;
-    s.kind = PcStep::TILE;
-    s.d_levels = dev_upload(levels.data(), levels.size());
-    s.nlevels = (int)levels.size();
-    s.its = its;
-    s.nphases = (int)(e - k);
-    out.push_back(s);
+    const int per_launch = its / std::max(1, tile_plan_.depth) + 2;   // hand-offs of a level, at most
+    auto tile_step = [&](const TileLevel *lv, int n, int nphases) {
+        PcStep s;
+        s.kind = PcStep::TILE;
+        s.d_levels = dev_upload(lv, (size_t)n);
+        s.nlevels = n;
+        s.its = its;
+        s.nphases = nphases;
+        s.epoch0 = tile_epoch_cursor_;
+        s.clear = !tile_cleared_;
+        tile_cleared_ = true;
+        tile_epoch_cursor_ += (uint32_t)(n * per_launch);
+        out.push_back(s);
+    };
+    if (tile_sweep_fuses_update(tile_plan_.W)) {
+        for (size_t q = k; q < e; ++q) (void)hipFree(steps_[q].rows.d_ops);
+        tile_step(levels.data(), (int)levels.size(), (int)(e - k));
+        return true;
+    }
+    // Wide rows: the kernel has no registers for the level update.  It stays the plain launch it
+    // was (it also leaves p_1, which the tile launch recomputes from the same right-hand side),
+    // and every level's Chebyshev steps become a tile launch of their own; the hand-off tags
+    // keep counting through the launches of an application.
+    for (size_t i = 0; i < run.size(); ++i) {
+        const SweepLevel &lv = *run[i];
+        TileLevel L = levels[i];
+        size_t first_cheb = lv.first;
+        if (L.n_upd > 0) {
+            out.push_back(steps_[lv.first]);         // the update, as a plain single-block step
+            first_cheb = lv.first + 1;
+            L.n_upd = 0;
+            L.prev_in_lds = 0;
+            L.bin = lv.b_after;
+            L.bout = nullptr;
+        }
+        for (size_t q = first_cheb; q < lv.last; ++q) (void)hipFree(steps_[q].rows.d_ops);
+        tile_step(&L, 1, (int)(lv.last - first_cheb));
+    }
     return true;
 }
 
@@ -394,6 +432,8 @@ void SchurPC::fuse_programs() {
     const bool tile_forced = pm_all && pm_all[0] == 't';
     const bool tile_wanted = tile_forced || !pm_all || pm_all[0] == 'a';
     const bool use_tiles = tile_wanted && prepare_tiles();
+    tile_epoch_cursor_ = 0;
+    tile_cleared_ = false;
     if (!legacy_tried_) {
         legacy_tried_ = true;
         legacy_ok_ = setup_row_programs();
@@ -850,6 +890,7 @@ void SchurPC::emit_update_and_solve(Lin upd, const Solve &sv, int its, double em
         // reads: the updated right-hand side stays on chip (nothing reads B_i after a sweep: the
         // next batched step overwrites it).
         L.bout = upd.y == upd.yin ? nullptr : upd.y;
+        lv.b_after = upd.y;
         L.out = sv.out;
         L.x_prev = upd.terms[0].x;
         L.n_upd = (int32_t)upd.terms.size();
@@ -1241,6 +1282,9 @@ void SchurPC::replay(size_t first, size_t last) {
                 const size_t words = 2 * (size_t)S_.patterns[m_pat_].nrows;
                 a.granule_bytes = (unsigned)(words * sizeof(unsigned long long));
                 a.err = d_err_;
+                a.epoch0 = s.epoch0;
+                a.clear = s.clear ? 1 : 0;
+                a.fused_update = tile_sweep_fuses_update(tp.W) ? 1 : 0;
                 a.stamps = S_.opt("stamps") != nullptr;
                 {
                     const char *dd = S_.opt("debug_drop_handoff");

@@ -39,6 +39,8 @@ struct PcStep {
     int gmode = 0;                  // PROG: 0 counters, 1 data-flow fixed width, 2 data-flow any width
     TileLevel *d_levels = nullptr;  // TILE: nlevels time levels of `its` steps each
     int nlevels = 0, its = 0;
+    uint32_t epoch0 = 0;            // TILE: first hand-off tag of this launch minus one
+    bool clear = false;             // TILE: zero the granule buffers first
 };
 
 // A device-resident pc_fn: reads the nullspace-corrected right-hand side from in(), leaves
@@ -154,12 +156,15 @@ class SchurPC : public PcBase {
         std::vector<TileCoef> coef;     // steps 2 .. its
         int its = 0;
         bool eligible = false;
+        const double *b_after = nullptr;   // the right-hand side after the update (B_i)
     };
     std::vector<SweepLevel> sweep_levels_;
     TilePlan tile_plan_;
     bool tile_tried_ = false, tile_ok_ = false;
     unsigned long long *d_tg_[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<void *> tile_owned_;    // coefficient tables of the current program
+    uint32_t tile_epoch_cursor_ = 0;    // hand-off tags handed out to the launches of one application
+    bool tile_cleared_ = false;
     bool prepare_tiles();
     bool fuse_tile_run(size_t k, size_t e, std::vector<PcStep> &out);
 

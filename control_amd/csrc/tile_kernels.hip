@@ -53,7 +53,7 @@ __device__ __forceinline__ void publish(const __amdgpu_buffer_rsrc_t rs, int gro
     __builtin_amdgcn_raw_buffer_store_b128(g, rs, grow * 16, 0, 16 /* sc1 */);
 }
 
-template <int W, int RPT, int TMAX>
+template <int W, int RPT, int TMAX, bool UPD>
 __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     const TileArgs A, const TileLevel *__restrict__ levels, const int32_t *__restrict__ n_all,
     const int32_t *__restrict__ grow_all, const uint16_t *__restrict__ lcol_all,
@@ -67,7 +67,12 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     const int32_t *nt = n_all + (size_t)tile * (TILE_DEPTH_MAX + 1);
     const int n0 = nt[0], nk = nt[depth], nk1 = nt[depth - 1];
     if (tid <= TILE_DEPTH_MAX) sn[tid] = nt[tid];
-    if (tid == 0) sdead = 0;
+    if (tid == 0) {
+        sdead = 0;
+        // the zero slot: what columns of boundary rows read (their iterates are exactly 0)
+        X[nkp - 1] = 0.0;
+        X[2 * (size_t)nkp - 1] = 0.0;
+    }
     const gci_p grow = (gci_p)grow_all + (size_t)tile * nkp;
     const gcb_p rowmask = (gcb_p)rowmask_;
 
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     double *scoef = X + 2 * (size_t)nkp;
     const void *coef_key = nullptr;
     int cur = 0;             // X + cur * nkp: the newest iterate; the other half: the one before
-    unsigned epoch = 0;
+    unsigned epoch = A.epoch0;   // tags never repeat between the launches of one application
     bool dead = false;       // a spin timed out: stop waiting, run to the end, results invalid
     const void *vals_key = nullptr;
     double v[RPT][W];
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
 #pragma unroll
         for (int sl = 0; sl < RPT; ++sl) {
             const int r = sl * T + tid;
-            if (r < n0 && !(tile == 0 && A.debug_drop > 0 && (int)epoch == A.debug_drop)) {
+            if (r < n0 && !(tile == 0 && A.debug_drop > 0 && (int)(epoch - A.epoch0) == A.debug_drop)) {
                 publish(rn, gr[sl], Xc[r], epoch);
                 if (both) publish(ro, gr[sl], Xo[r], epoch);
             }
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
         int cr;
         {
             double *Xc = X + cur * nkp, *Xo = X + (cur ^ 1) * nkp;
-            if (L.n_upd > 0) {
+            if (UPD && L.n_upd > 0) {
                 if (!L.prev_in_lds) {
                     // produced before this launch (or by another rank): plain memory
                     const gcd_p xp = (gcd_p)L.x_prev;
@@ -454,28 +459,33 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
 
 typedef void (*tile_fn)(const TileArgs, const TileLevel *, const int32_t *, const int32_t *,
                         const uint16_t *, const int32_t *, const uint8_t *);
-// Register budget per thread by workgroup size: 512 threads -> 256, 768 -> 168, 1024 -> 128.
-// Narrow rows (2-D P1) run 512 threads with up to three row slots or 1 024 with one; wide rows
-// (3-D P1: 15 entries, 30 registers of matrix values per row slot) run 768 threads with two.
+// Register budget per thread by workgroup size: 512 threads -> 256, 1024 -> 128.  Narrow rows
+// (2-D P1) run 512 threads with up to three row slots or 1 024 with one, level update fused.
+// Wide rows (3-D P1: 15 entries, 30 registers of matrix values per row slot) run 512 threads with
+// two slots in the variant without the fused update (244 registers; with it 256 + 78 spilled).
 static tile_fn pick_tile(int W, int rpt, int threads) {
-#define KKT_T(w)                                                                         \
-    if (W == w) {                                                                        \
-        if (threads <= 512) {                                                            \
-            switch (rpt) {                                                               \
-                case 1: return pc_tile_sweep<w, 1, 512>;                                 \
-                case 2: return pc_tile_sweep<w, 2, 512>;                                 \
-                case 3: return w <= 9 ? pc_tile_sweep<(w <= 9 ? w : 5), 3, 512> : nullptr; \
-                default: return nullptr;                                                 \
-            }                                                                            \
-        }                                                                                \
-        if (threads <= 768) return rpt == 1 ? pc_tile_sweep<w, 1, 768>                    \
-                                   : rpt == 2 ? pc_tile_sweep<w, 2, 768> : nullptr;      \
-        return rpt == 1 ? pc_tile_sweep<w, 1, 1024> : nullptr;                           \
+#define KKT_T(w)                                                           \
+    if (W == w) {                                                          \
+        if (threads <= 512) {                                              \
+            switch (rpt) {                                                 \
+                case 1: return pc_tile_sweep<w, 1, 512, true>;             \
+                case 2: return pc_tile_sweep<w, 2, 512, true>;             \
+                case 3: return pc_tile_sweep<w, 3, 512, true>;             \
+                default: return nullptr;                                   \
+            }                                                              \
+        }                                                                  \
+        return rpt == 1 ? pc_tile_sweep<w, 1, 1024, true> : nullptr;       \
     }
-    KKT_T(5) KKT_T(7) KKT_T(9) KKT_T(15)
+    KKT_T(5) KKT_T(7) KKT_T(9)
 #undef KKT_T
+    if (W == 15 && threads <= 512) {
+        if (rpt == 1) return pc_tile_sweep<15, 1, 512, false>;
+        if (rpt == 2) return pc_tile_sweep<15, 2, 512, false>;
+    }
     return nullptr;
 }
+
+bool tile_sweep_fuses_update(int W) { return W <= 9; }
 
 size_t tile_sweep_lds_bytes(int nk_pad, int its) {
     return (2 * (size_t)nk_pad + 3 * (size_t)std::max(1, its - 1)) * sizeof(double);
@@ -505,11 +515,12 @@ void launch_tile_sweep(hipStream_t s, const TileArgs &a, const TileLevel *d_leve
                        const int32_t *d_gpos, const uint8_t *d_rowmask, int ntiles, int threads,
                        size_t granule_words) {
     if (a.nlevels <= 0 || ntiles <= 0) return;
-    // tags of an earlier launch must not match this launch's epochs
-    for (int i = 0; i < 2; ++i) {
-        (void)hipMemsetAsync(a.gnew[i], 0, granule_words * sizeof(unsigned long long), s);
-        (void)hipMemsetAsync(a.gold[i], 0, granule_words * sizeof(unsigned long long), s);
-    }
+    // tags of an earlier application must not match this one's hand-off numbers
+    if (a.clear)
+        for (int i = 0; i < 2; ++i) {
+            (void)hipMemsetAsync(a.gnew[i], 0, granule_words * sizeof(unsigned long long), s);
+            (void)hipMemsetAsync(a.gold[i], 0, granule_words * sizeof(unsigned long long), s);
+        }
     const size_t lds = tile_sweep_lds_bytes(a.nk_pad, a.its);
     hipLaunchKernelGGL(pick_tile(a.W, a.rpt, threads), dim3(ntiles), dim3(threads), lds, s, a, d_levels,
                        d_n, d_grow, d_lcol, d_gpos, d_rowmask);

@@ -17,6 +17,8 @@ struct Bisector {
     std::vector<int32_t> stamp, dist, queue;
     int32_t cur = 0;
 
+    // (rows left out of the partition never carry the current stamp, so the searches pass
+    // around them)
     Bisector(const Pattern &P_, std::vector<int32_t> &part_)
         : P(P_), part(part_), stamp(P_.nrows, 0), dist(P_.nrows, 0) {
         queue.reserve(P_.nrows);
@@ -101,7 +103,7 @@ void TilePlan::release() {
 }
 
 bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int max_rpt,
-                     TilePlan &out) {
+                     TilePlan &out, const uint8_t *mask) {
     if (P.nrows != P.ncols || ntiles < 1 || depth > TILE_MAX_DEPTH) return false;
     const bool auto_depth = depth <= 0;
     if (auto_depth) depth = TILE_MAX_DEPTH;
@@ -113,11 +115,15 @@ bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int m
     out.threads = threads;
     out.W = P.max_width;
     if (out.W < 1) return false;
-    out.part.assign(nrows, 0);
+    out.part.assign(nrows, -1);
     {
         Bisector B(P, out.part);
-        std::vector<int32_t> all(nrows);
-        std::iota(all.begin(), all.end(), 0);
+        std::vector<int32_t> all;
+        all.reserve(nrows);
+        for (int64_t r = 0; r < nrows; ++r)
+            if (!mask || !mask[r]) all.push_back((int32_t)r);
+        if ((int64_t)ntiles > (int64_t)all.size()) ntiles = (int)std::max<size_t>(1, all.size());
+        out.ntiles = ntiles;
         B.run(all, ntiles, 0);
     }
     // rings: L_0 = own rows, L_{j+1} = L_j + columns of the rows of L_j
@@ -125,7 +131,8 @@ bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int m
     out.n.assign((size_t)ntiles * (TILE_MAX_DEPTH + 1), 0);
     {
         std::vector<std::vector<int32_t>> own(ntiles);
-        for (int64_t r = 0; r < nrows; ++r) own[out.part[r]].push_back((int32_t)r);
+        for (int64_t r = 0; r < nrows; ++r)
+            if (out.part[r] >= 0) own[out.part[r]].push_back((int32_t)r);
         std::vector<int32_t> mark(nrows, -1);
         for (int t = 0; t < ntiles; ++t) {
             std::vector<int32_t> &L = local[t];
@@ -140,7 +147,7 @@ bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int m
                 for (size_t i = first; i < last; ++i)
                     for (int32_t q = P.h_indptr[L[i]]; q < P.h_indptr[L[i] + 1]; ++q) {
                         const int32_t c = P.h_indices[q];
-                        if (mark[c] != t) {
+                        if (mark[c] != t && !(mask && mask[c])) {
                             mark[c] = t;
                             ring.push_back(c);
                         }
@@ -212,13 +219,13 @@ bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int m
     out.max_rows = max_rows;
     out.max_halo = max_halo;
     out.mean_redundancy = red / ntiles;
-    if (max_nk > 65535) return false;
+    if (max_nk + 64 > 65535) return false;
     int rpt = (int)((max_rows + threads - 1) / threads);
     while ((int64_t)(rpt + 1) * threads < max_halo) ++rpt;
     if (rpt < 1) rpt = 1;
     if (rpt > max_rpt) return false;
     out.rpt = rpt;
-    out.nk_pad = (int)((max_nk + 63) & ~(int64_t)63);
+    out.nk_pad = (int)((max_nk + 1 + 63) & ~(int64_t)63);   // + the zero slot at nk_pad - 1
     const int W = out.W, T = threads;
     out.grow.assign((size_t)ntiles * out.nk_pad, -1);
     out.lcol.assign((size_t)ntiles * rpt * W * T, 0);
@@ -243,7 +250,7 @@ bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int m
                     const int32_t c = P.h_indices[P.h_indptr[g] + k];
                     // (timing experiment only, results wrong: every gather hits the own row)
                     static const bool nogather = std::getenv("KKT_TILE_NOGATHER") != nullptr;
-                    out.lcol[at] = (uint16_t)(nogather ? r : lidx[c]);
+                    out.lcol[at] = (uint16_t)(nogather ? r : (mask && mask[c]) ? out.nk_pad - 1 : lidx[c]);
                     out.gpos[at] = (int32_t)P.sell_index(g, k);
                 } else {
                     out.lcol[at] = (uint16_t)(live ? r : 0);   // value 0: any valid index
@@ -259,7 +266,8 @@ bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int m
         std::vector<std::set<int32_t>> reads(ntiles);
         for (int t = 0; t < ntiles; ++t) {
             const int32_t *nt = &out.n[(size_t)t * (TILE_MAX_DEPTH + 1)];
-            for (int l = nt[0]; l < nt[depth]; ++l) reads[t].insert(out.part[local[t][l]]);
+            for (int l = nt[0]; l < nt[depth]; ++l)
+                if (out.part[local[t][l]] >= 0) reads[t].insert(out.part[local[t][l]]);
         }
         out.symmetric = true;
         for (int t = 0; t < ntiles && out.symmetric; ++t)

@@ -49,7 +49,10 @@ struct TilePlan {
 // steps on the shrinking region) among those that fit.  Returns false when the structure does
 // not fit the kernel's limits (local indices are 16-bit; `threads` * max_rpt rows per tile;
 // threads * (max_rpt + 1) halo rows).
+// `mask` (may be null): rows with mask[r] != 0 -- Dirichlet rows, whose iterates are exactly zero
+// and whose columns are zeroed in every matrix of a sweep -- belong to no tile and to no ring;
+// columns that point at them read the tile's permanent zero slot (local index nk_pad - 1).
 bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int max_rpt,
-                     TilePlan &out);
+                     TilePlan &out, const uint8_t *mask = nullptr);
 
 }  // namespace kkt

@@ -43,8 +43,17 @@ int main(int argc, char **argv) {
     P.nslices = (n + 127) / 128;
     for (int s = 0; s <= P.nslices; ++s) P.h_slice_off.push_back(7 * s);
     P.npadded = (int64_t)7 * P.nslices * 128;
+    // boundary rows: masked (their iterates are zero); argv[8] = 0 keeps them inside the tiles
+    std::vector<uint8_t> mask(n, 0);
+    for (int j = 0; j < ny; ++j)
+        for (int i = 0; i < nx; ++i)
+            if (i == 0 || j == 0 || i == nx - 1 || j == ny - 1) mask[j * nx + i] = 1;
+    const bool mask_aware = argc > 8 ? std::atoi(argv[8]) != 0 : true;
     TilePlan tp;
-    if (!build_tile_plan(P, ntiles, depth_in, T, 4, tp)) { std::printf("plan does not fit\n"); return 3; }
+    if (!build_tile_plan(P, ntiles, depth_in, T, 4, tp, mask_aware ? mask.data() : nullptr)) {
+        std::printf("plan does not fit\n");
+        return 3;
+    }
     std::printf("plan: %d tiles depth %d rpt %d nk_pad %d symmetric %d max own %lld rows %lld halo %lld red %.2f\n",
                 tp.ntiles, tp.depth, tp.rpt, tp.nk_pad, (int)tp.symmetric, (long long)tp.max_own,
                 (long long)tp.max_rows, (long long)tp.max_halo, tp.mean_redundancy);
@@ -53,10 +62,6 @@ int main(int argc, char **argv) {
     std::mt19937_64 rng(7);
     std::uniform_real_distribution<double> U(-1.0, 1.0);
     // SELL value arrays per level (F) and update matrices, masks
-    std::vector<uint8_t> mask(n, 0);
-    for (int j = 0; j < ny; ++j)
-        for (int i = 0; i < nx; ++i)
-            if (i == 0 || j == 0 || i == nx - 1 || j == ny - 1) mask[j * nx + i] = 1;
     auto rand_vals = [&]() {
         std::vector<double> v(P.npadded, 0.0);
         for (int r = 0; r < n; ++r)
@@ -129,6 +134,7 @@ int main(int argc, char **argv) {
     // ---- emulation of the kernel, tiles in lock step
     const int NT = tp.ntiles;
     std::vector<std::vector<double>> X(NT, std::vector<double>(2 * (size_t)nkp, NAN));
+    for (int t = 0; t < NT; ++t) X[t][nkp - 1] = X[t][2 * (size_t)nkp - 1] = 0.0;   // zero slot
     std::vector<int> cur(NT, 0);
     std::vector<std::vector<double>> bl(NT, std::vector<double>((size_t)RPT * T, NAN));
     std::vector<double> Gn(n, NAN), Go(n, NAN);   // granule buffers (values), tags implied by lock step
@@ -193,6 +199,7 @@ int main(int argc, char **argv) {
                 }
                 // rows beyond the valid region are stale: poison them so that a wrong read shows
                 for (int r = nv; r < nt(t, depth); ++r) Xo[r] = NAN;
+                Xo[nkp - 1] = 0.0;
                 cur[t] ^= 1;
             }
             --cr;

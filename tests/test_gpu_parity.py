@@ -378,3 +378,24 @@ def test_minres_reports_an_indefinite_preconditioner_and_refuses_right_side():
     with pytest.raises(Exception, match="left preconditioning"):
         gsys.solve(np.zeros((m, nx)), np.zeros((m, nx)), b[:m], b[m:],
                    solver_parameters=dict(sp, pc_side="right"))
+
+
+@pytest.mark.parametrize("CN", [False, True])
+def test_preconditioner_parity_3d_tile_form(CN):
+    """3-D P1 (15 entries per row): the tile form without the fused update -- one plain launch
+    for b -= U u_prev and one tile launch per time level, hand-off tags counting through the
+    launches -- against the oracle and, bit for bit, against the plain launches."""
+    p = common.heat_problem(space="p1_3d", n=16, n_t=5, CN=CN)
+    osys = common.oracle_system(p)
+    mass, schur = (20, 0.5, 2.5), (7, 0.05, 2.1)
+    x = common.rng_vector(osys.N)
+    ref = osys.pc_apply(common.oracle_pc(p, mass, schur), x)
+    g = common.gpu_system(p, options={"prog_mode": "tile"})
+    got = g.pc_apply(x, common.gpu_pc(p, mass, schur))
+    assert common.rel_err(got, ref) < 1e-10
+    again = g.pc_apply(x, common.gpu_pc(p, mass, schur))      # replay: tags of the first run are stale
+    assert np.array_equal(got, again)
+    plain = common.gpu_system(p, options={"persistent": "0"}).pc_apply(
+        x, common.gpu_pc(p, mass, schur))
+    assert np.array_equal(got, plain)
+    assert g.info()["program_fallbacks"] == 0
