@@ -482,6 +482,8 @@ static tile_fn pick_tile(int W, int rpt, int threads) {
         if (rpt == 1) return pc_tile_sweep<15, 1, 512, false>;
         if (rpt == 2) return pc_tile_sweep<15, 2, 512, false>;
     }
+    // P2 velocity blocks (9 or 19 entries per row, row-sorted storage): one row slot
+    if (W == 19 && threads <= 512 && rpt == 1) return pc_tile_sweep<19, 1, 512, false>;
     return nullptr;
 }
 
