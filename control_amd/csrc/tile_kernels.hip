@@ -172,7 +172,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
 #pragma unroll
         for (int h = 0; h < HPT; ++h) {
             want_o[h] = both && hl[h] >= 0 && hl[h] < nk1;
-            na[h] = nb[h] = oa[h] = ob[h] = (unsigned long long)epoch << 32;
+            na[h] = nb[h] = oa[h] = ob[h] = 0ull;       // tag 0 never matches a hand-off number
         }
         // a poll samples memory about half a round trip after it is issued; the neighbours'
         // granules, stored at about the same time as this tile's, take about one: polling at
@@ -181,23 +181,27 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
         unsigned spins = 0;
         while (true) {
             bool ok = true;
+            // only what has not arrived yet is requested again
 #pragma unroll
             for (int h = 0; h < HPT; ++h) {
-                if (hl[h] >= 0) {
+                if (hl[h] >= 0 && ((unsigned)(na[h] >> 32) != epoch || (unsigned)(nb[h] >> 32) != epoch)) {
                     const gu64_p g = gn + 2 * (size_t)hg[h];
                     na[h] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     nb[h] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (want_o[h]) {
+                if (want_o[h] && ((unsigned)(oa[h] >> 32) != epoch || (unsigned)(ob[h] >> 32) != epoch)) {
                     const gu64_p g = go + 2 * (size_t)hg[h];
                     oa[h] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ob[h] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
 #pragma unroll
-            for (int h = 0; h < HPT; ++h)
-                ok &= (unsigned)(na[h] >> 32) == epoch && (unsigned)(nb[h] >> 32) == epoch &&
-                      (unsigned)(oa[h] >> 32) == epoch && (unsigned)(ob[h] >> 32) == epoch;
+            for (int h = 0; h < HPT; ++h) {
+                if (hl[h] >= 0)
+                    ok &= (unsigned)(na[h] >> 32) == epoch && (unsigned)(nb[h] >> 32) == epoch;
+                if (want_o[h])
+                    ok &= (unsigned)(oa[h] >> 32) == epoch && (unsigned)(ob[h] >> 32) == epoch;
+            }
             if (ok || dead) break;
             if (++spins >= TILE_SPIN_LIMIT) {
                 // record who waited for what: tile, epoch, local index, global row, tags seen
@@ -209,8 +213,8 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                     for (int h = 0; h < HPT; ++h)
                         if (hl[h] >= 0 && ((unsigned)(na[h] >> 32) != epoch ||
                                            (unsigned)(nb[h] >> 32) != epoch ||
-                                           (unsigned)(oa[h] >> 32) != epoch ||
-                                           (unsigned)(ob[h] >> 32) != epoch)) {
+                                           (want_o[h] && ((unsigned)(oa[h] >> 32) != epoch ||
+                                                          (unsigned)(ob[h] >> 32) != epoch)))) {
                             A.err[8] = (unsigned)tile;
                             A.err[9] = epoch;
                             A.err[10] = (unsigned)hl[h];

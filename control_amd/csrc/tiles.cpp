@@ -164,7 +164,7 @@ bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int m
     // (fitted to per-tile timings on MI355X, 256^2 P1, depths 2 .. 10, DESIGN.md section 6: a
     // hand-off costs 1.5 us + 1.9 us per 1 000 granule pairs gathered -- the newest iterate on all
     // rings, the previous one on all but the outermost --, a local step 0.30 us + 0.23 us per
-    // 1 000 rows computed; 1 024-thread workgroups: 1.3 + 2.6 and 0.37 + 0.06).
+    // 1 000 rows computed; 1 024-thread workgroups: 1.15 + 2.4 and 0.37 + 0.06).
     auto model = [&](int d, double *us) -> bool {
         int64_t mk = 0, mr = 0, mh = 0, mo = 0;
         for (int t = 0; t < ntiles; ++t) {
@@ -178,7 +178,7 @@ bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int m
         while ((int64_t)(rp + 1) * threads < mh) ++rp;
         if (mk > 65535 || rp > max_rpt) return false;
         const bool big = threads > 512;
-        const double handoff = (big ? 1.3 : 1.5) + (big ? 2.6e-3 : 1.9e-3) * (double)(mh + mo);
+        const double handoff = (big ? 1.15 : 1.5) + (big ? 2.4e-3 : 1.9e-3) * (double)(mh + mo);
         const double step = big ? 0.37 + 0.06e-3 * (double)mr : 0.30 + 0.23e-3 * (double)mr;
         *us = (handoff + d * step) / d;
         return true;

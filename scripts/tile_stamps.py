@@ -8,9 +8,10 @@ from control_amd import problems as common
 import bench
 
 class A: pass
-a = A(); a.workload = "heat2d"; a.n = int(os.environ.get("N", 256)); a.n_t = 64; a.beta = 1e-4
+a = A(); a.workload = os.environ.get("WORKLOAD", "heat2d"); a.n = int(os.environ.get("N", 256))
+a.n_t = int(os.environ.get("N_T", 64)); a.beta = 1e-4
 a.T = 2.0; a.scheme = "BE"; a.mode = "G"
-a.schur_its = int(os.environ.get("ITS", 80)); a.schur_emin = 7e-4; a.schur_emax = 2.1
+a.schur_its = int(os.environ.get("ITS", 80)); a.schur_emin = float(os.environ.get("EMIN", 7e-4)); a.schur_emax = 2.1
 p = bench.build_problem(a)
 opts = {"stamps": "1", "no_graph": "1"}
 for k in ("tile_depth", "tile_waves", "tile_poll_delay"):
