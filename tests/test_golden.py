@@ -69,3 +69,36 @@ def test_gpu_matches_golden(CN):
             assert abs(r.its - int(g[f"{ksp}_its"])) <= 1
             if ksp == "fgmres":
                 assert common.rel_err(np.vstack([u0, u1]), g[f"{ksp}_solution"]) < 1e-5
+
+
+def test_smoke_histories_on_record():
+    """tests/golden/smoke_histories.npz holds the FGMRES residual histories of the smoke problem
+    from the oracle AND from the HIP path (made on an MI355X by make_smoke_histories.py).  CN: the
+    two agree iterate for iterate; BE: they separate (classical Gram-Schmidt on an
+    ill-conditioned preconditioned operator), stop after different iteration counts and reach
+    the same solution.  The oracle must keep reproducing its own history."""
+    g = np.load(os.path.join(HERE, "golden", "smoke_histories.npz"))
+    ho, hg = g["CN_oracle_history"], g["CN_gpu_history"]
+    assert len(ho) == len(hg)
+    # (relative to the norm itself down to 1e-9 of the first one; below that the norms are
+    # round-off of the recurrence)
+    assert np.all(np.abs(ho - hg) <= 1e-6 * ho + 1e-9 * ho[0])
+    assert common.rel_err(g["CN_gpu_solution"], g["CN_oracle_solution"]) < 1e-8
+    ho, hg = g["BE_oracle_history"], g["BE_gpu_history"]
+    assert np.max(np.abs(ho[:3] - hg[:3]) / ho[:3]) < 1e-9          # identical start ...
+    assert len(ho) != len(hg) or np.max(np.abs(ho - hg) / ho) > 1e-6    # ... then they separate
+    assert common.rel_err(g["BE_gpu_solution"], g["BE_oracle_solution"]) < 1e-7
+    for CN in (True,):
+        p = common.heat_problem(n=10, n_t=10, CN=CN, beta=1e-2)
+        osys = common.oracle_system(p)
+        m, nx = p["m"], p["sd"].n_dofs
+        b = common.rng_vector(osys.N).reshape(2 * m, nx)
+        sp = {"linear_solver": "fgmres", "fgmres_restart": 10, "maximum_iterations": 300,
+              "relative_tolerance": 1e-9, "absolute_tolerance": 0.0,
+              "monitor_convergence": False, "preconditioner": True}
+        u0, u1 = np.zeros((m, nx)), np.zeros((m, nx))
+        r = osys.solve(u0, u1, b[:m], b[m:], solver_parameters=sp,
+                       pc_fn=common.oracle_pc(p, MASS, KSCHUR))
+        h = np.asarray(r.history)
+        assert len(h) == len(g["CN_oracle_history"])
+        assert np.all(np.abs(h - g["CN_oracle_history"]) <= 1e-6 * h + 1e-9 * h[0])
