@@ -390,16 +390,19 @@ def measure_heat(args, rank, world, local_rank, tts):
             alg_sw = sw_ph.value * S_bytes
             sweeps = {
                 "kernel": "sweep programs (the time sweeps of one preconditioner application)",
-                "bound": "hbm", "achieved": alg_sw / (sw_ms.value * 1e-3) / 1e9,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": alg_sw / (sw_ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "bound": "latency (hand-offs between dependent SpMV steps; operands on chip)",
                 "launches": sw_n.value, "phases": int(sw_ph.value), "total_ms": sw_ms.value,
                 "us_per_phase": 1e3 * sw_ms.value / sw_ph.value,
-                "algorithmic_bytes": int(alg_sw),
-                "note": "algorithmic bytes = SpMV steps x S, S = 12 nnz + 4 (N_x + 1) + 16 N_x of "
-                        "one spatial block (SURVEY 8d, B_pc); matrix, diagonal and iterates stay "
-                        "on chip (registers / LDS), so the launch moves far fewer bytes and is "
-                        "bound by the hand-off latency between dependent steps, not by HBM"}
+                "traffic": None, "hbm_GBs": None, "hbm_frac": None,
+                "bytes_if_streamed": int(alg_sw),
+                "GBs_if_streamed": alg_sw / (sw_ms.value * 1e-3) / 1e9,
+                "note": "traffic = HBM bytes of all sweep launches of one application from the "
+                        "committed PMC passes, hbm_GBs = traffic / total_ms, hbm_frac = hbm_GBs / "
+                        f"{HBM_PEAK_GBS:.0f}: matrix, diagonal and iterates stay on chip (registers "
+                        "/ LDS), the launches are bound by the hand-off latency between dependent "
+                        "steps, not by HBM.  *_if_streamed = what plain launches would stream: "
+                        "SpMV steps x S, S = 12 nnz + 4 (N_x + 1) + 16 N_x of one spatial block "
+                        "(SURVEY 8d, B_pc); a side figure, not a fraction of anything"}
 
     # ---- Krylov leg: W warm-up iterations, then exactly K timed ones
     d_b, d_u = dvec(x), dvec()
@@ -496,7 +499,10 @@ def measure_heat(args, rank, world, local_rank, tts):
         # HBM-side bytes of one application (all sweep launches) from the committed PMC passes
         per_launch = measured_sweep_traffic(workload, out["config"]["preconditioner"],
                                             sweeps["phases"] // sweeps["launches"])
-        sweeps["traffic"] = None if per_launch is None else per_launch * sweeps["launches"]
+        if per_launch is not None:
+            sweeps["traffic"] = per_launch * sweeps["launches"]
+            sweeps["hbm_GBs"] = sweeps["traffic"] / (sweeps["total_ms"] * 1e-3) / 1e9
+            sweeps["hbm_frac"] = sweeps["hbm_GBs"] / HBM_PEAK_GBS
         out["roofline_sweeps"] = sweeps
     return out
 

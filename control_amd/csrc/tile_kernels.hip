@@ -281,8 +281,69 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     };
     if (A.nlevels > 0) load_level(levels[0]);
 
+    // Narrow rows leave registers for the NEXT level's operands (its matrix, the matrix of its
+    // update, diagonal, right-hand side): they are requested when the last round of local steps
+    // of a level begins and land under those steps.  Requested at the level's end they cost an
+    // HBM round trip per level twice over -- once in front of the hand-off's polls (loads return
+    // in order), once in front of the update (measured: 3 us of level prologue in mode G).
+    constexpr bool PRE = UPD && W * RPT <= 14 && TMAX <= 512;
+    constexpr int PR = PRE ? RPT : 1, PW = PRE ? W : 1;
+    double vn[PR][PW], un[PR][PW], dn[PR], bn[PR];
+    bool pre_v = false, pre_u = false, pre_issued = false;
+    auto prefetch_level = [&](const TileLevel &N) {
+        if constexpr (PRE) {
+            pre_issued = true;
+            pre_v = (const void *)N.vals != vals_key;
+            if (pre_v) {
+                const gcd_p vp = (gcd_p)N.vals;
+#pragma unroll
+                for (int sl = 0; sl < RPT; ++sl)
+#pragma unroll
+                    for (int k = 0; k < W; ++k) {
+                        const int gp = KKT_GP(sl, k);
+                        vn[sl][k] = gp >= 0 ? vp[gp] : 0.0;
+                    }
+            }
+            pre_u = N.n_upd > 0;
+            if (pre_u) {
+                const gcd_p up = (gcd_p)N.upd_vals[0];
+#pragma unroll
+                for (int sl = 0; sl < RPT; ++sl)
+#pragma unroll
+                    for (int k = 0; k < W; ++k) {
+                        const int gp = KKT_GP(sl, k);
+                        un[sl][k] = (gr[sl] >= 0 && gp >= 0) ? up[gp] : 0.0;
+                    }
+            }
+            const gcd_p dp = (gcd_p)N.dinv, bp = (gcd_p)N.bin;
+#pragma unroll
+            for (int sl = 0; sl < RPT; ++sl) {
+                dn[sl] = gr[sl] >= 0 ? dp[gr[sl]] : 0.0;
+                bn[sl] = gr[sl] >= 0 ? bp[gr[sl]] : 0.0;
+            }
+        }
+    };
+    auto adopt_level = [&](const TileLevel &N) {
+        if constexpr (PRE) {
+            if (pre_v) {
+                vals_key = (const void *)N.vals;
+#pragma unroll
+                for (int sl = 0; sl < RPT; ++sl)
+#pragma unroll
+                    for (int k = 0; k < W; ++k) v[sl][k] = vn[sl][k];
+            }
+#pragma unroll
+            for (int sl = 0; sl < RPT; ++sl) {
+                dinv[sl] = dn[sl];
+                b[sl] = bn[sl];
+            }
+        }
+    };
+
     for (int lev = 0; lev < A.nlevels; ++lev) {
         const TileLevel &L = levels[lev];
+        const bool have_u = PRE && pre_issued && pre_u;   // un holds the values of upd_vals[0]
+        pre_issued = false;
         if ((const void *)L.coef != coef_key) {
             coef_key = (const void *)L.coef;
             const gcd_p cp = (gcd_p)(const double *)L.coef;
@@ -315,11 +376,22 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                 double acc[RPT];
 #pragma unroll
                 for (int sl = 0; sl < RPT; ++sl) acc[sl] = 0.0;
-                for (int t = 0; t < L.n_upd; ++t) {
+                if constexpr (PRE) {
+                    if (have_u) {
+#pragma unroll
+                        for (int sl = 0; sl < RPT; ++sl) {
+                            if (sl * T + (tid & ~63) >= nk1) continue;
+#pragma unroll
+                            for (int k = 0; k < W; ++k)
+                                acc[sl] = __builtin_fma(un[sl][k], Xc[KKT_COL(sl, k)], acc[sl]);
+                        }
+                    }
+                }
+                for (int t = have_u ? 1 : 0; t < L.n_upd; ++t) {
                     const gcd_p up = (gcd_p)L.upd_vals[t];
 #pragma unroll
                     for (int sl = 0; sl < RPT; ++sl) {
-                        if (sl * T >= nk1) continue;
+                        if (sl * T + (tid & ~63) >= nk1) continue;
 #pragma unroll
                         for (int k0 = 0; k0 < W; k0 += CH) {
                             int gp[CH];
@@ -376,6 +448,8 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
             lds_barrier();
             cur ^= 1;
         }
+        const bool has_next = lev + 1 < A.nlevels;
+        if (PRE && has_next && its - 1 <= cr) prefetch_level(levels[lev + 1]);
 #pragma unroll
         for (int sl = 0; sl < RPT; ++sl) {
             asm volatile("" : "+v"(dinv[sl]));
@@ -391,6 +465,8 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
             if (cr == 0) {
                 handoff(s >= 3);
                 cr = depth;
+                // the last round of the level: the next level's operands travel under it
+                if (PRE && has_next && its - s < depth) prefetch_level(levels[lev + 1]);
             }
             const int nv = nv_next;
             const double cf1 = cn1, cf2 = cn2, cf3 = cn3;
@@ -400,7 +476,9 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
             double *Xc = X + cur * nkp, *Xo = X + (cur ^ 1) * nkp;
 #pragma unroll
             for (int sl = 0; sl < RPT; ++sl) {
-                if (sl * T >= nv) continue;          // wave-uniform: nothing of this slot is live
+                // wave-uniform: none of this wave's 64 rows of the slot is live on the shrunken
+                // region (the step is bound by the LDS gathers of the whole workgroup)
+                if (sl * T + (tid & ~63) >= nv) continue;
                 const int r = sl * T + tid;
                 double acc = 0.0;
 #pragma unroll
@@ -451,8 +529,9 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
             }
             if (lev + 1 < A.nlevels) {
                 const TileLevel &N = levels[lev + 1];
-                load_level(N);
+                if (!(PRE && pre_issued)) load_level(N);
                 if (N.n_upd > 0 && N.prev_in_lds) handoff(false);
+                if (PRE && pre_issued) adopt_level(N);
             }
         }
     }

@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Copy what scripts/r02_profiles.sh left under gpurun_out/r02_prof into profiles/r02 (tracked):
+bench lines, rocprofv3 kernel/domain stats, the PMC rows of the two kernels the bench line
+prices (FETCH_SIZE / WRITE_SIZE passes), and the per-launch HBM traffic derived from them
+(corrected as MI355X_MICROARCH.md prescribes: on gfx950 FETCH_SIZE reports half of the bytes of
+16 B/lane streaming reads -- only the matrix-value stream of kkt_spmv_rows is such a read).
+
+Run here after a gpurun call of scripts/r02_profiles.sh:  python scripts/r02_collect_profiles.py
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r02_prof")
+DST = os.path.join(ROOT, "profiles", sys.argv[2] if len(sys.argv) > 2 else "r02")
+os.makedirs(DST, exist_ok=True)
+
+for name in ("bench_r02.json", "bench_under_rocprof.json", "other_configs.jsonl",
+             "bench_stokes2d.json", "pmc_summary.json"):
+    if os.path.exists(os.path.join(SRC, name)):
+        shutil.copy(os.path.join(SRC, name), os.path.join(DST, name))
+for kind in ("kernel_stats", "domain_stats"):
+    f = glob.glob(os.path.join(SRC, "heat", "**", f"*{kind}.csv"), recursive=True)
+    if f:
+        shutil.copy(f[0], os.path.join(DST, f"bench_{kind}.csv"))
+
+bench = json.load(open(os.path.join(SRC, "bench_r02.json")))
+workload = bench["config"]["workload"]
+precond = bench["config"]["preconditioner"]
+
+
+def rows_of(counter, key):
+    out, header = [], None
+    for f in glob.glob(os.path.join(SRC, counter, "**", "*counter_collection.csv"), recursive=True):
+        rd = csv.reader(open(f))
+        header = next(rd)
+        ci, ki = header.index("Counter_Name"), header.index("Kernel_Name")
+        out += [r for r in rd if r[ci] == counter and key in r[ki]]
+    return header, out
+
+
+stats = {}
+for key in ("kkt_spmv_rows", "pc_tile_sweep"):
+    for counter, tag in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+        header, rows = rows_of(counter, key)
+        if not rows:
+            continue
+        with open(os.path.join(DST, f"pmc_{tag}_{key}.csv"), "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(header)
+            w.writerows(rows)
+        vi, ni = header.index("Counter_Value"), header.index("Kernel_Name")
+        vals = [float(r[vi]) * 1024.0 for r in rows]          # the counters are in KiB
+        stats[(key, tag)] = (sum(vals) / len(vals), len(vals), rows[0][ni])
+
+if ("kkt_spmv_rows", "fetch") in stats:
+    fetch, n, kname = stats[("kkt_spmv_rows", "fetch")]
+    write = stats[("kkt_spmv_rows", "write")][0]
+    # value stream: every value array once, padded SELL slots, 8 B each (bytes_streamed minus
+    # indices and vectors is not exported separately; recompute from the bench line)
+    info = bench["roofline"]
+    unknowns = bench["config"]["unknowns"]
+    # algorithmic = 8 nnz_pad * arrays + index bytes + 16 N; the index array of the one shared
+    # structure is small (1.85 MB), so value stream ~= algorithmic - 16 N - index bytes
+    value_stream = info["algorithmic_bytes_per_launch"] - 16 * unknowns
+    json.dump({
+        "workload": workload, "kernel": kname.split("(")[0].replace("void kkt::", ""),
+        "fetch_bytes_raw": fetch, "write_bytes": write,
+        "value_stream_bytes": value_stream,
+        "hbm_bytes_per_launch_corrected": fetch + 0.5 * value_stream + write,
+        "correction": "MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports 1/2 of the bytes of "
+                      "wide (16 B/lane) coalesced streaming reads; only the matrix-value stream of "
+                      "this kernel is such a read (algorithmic bytes minus 16 B per unknown; the "
+                      "shared index array is 1.85 MB), so half of it is added to the raw counter; "
+                      "index loads and x gathers (8 B/lane) are taken as reported; WRITE_SIZE is "
+                      "exact for the 16 B/lane y stores.",
+        "launches": n}, open(os.path.join(DST, "traffic_kkt_spmv_rows.json"), "w"), indent=1)
+
+if ("pc_tile_sweep", "fetch") in stats:
+    fetch, n, kname = stats[("pc_tile_sweep", "fetch")]
+    write = stats[("pc_tile_sweep", "write")][0]
+    sw = bench.get("roofline_sweeps") or {}
+    ppl = sw["phases"] // sw["launches"] if sw else None
+    json.dump({
+        "workload": workload, "preconditioner": precond,
+        "kernel": kname.split("(")[0].replace("void kkt::", ""),
+        "phases_per_launch": ppl, "fetch_bytes_raw": fetch, "write_bytes": write,
+        "hbm_bytes_per_launch": fetch + write, "launches": n,
+        "note": "raw FETCH_SIZE + WRITE_SIZE of one sweep launch: granule stores are 16 B/lane "
+                "write-through stores (exact), granule polls 8 B/lane sc1 loads and the per-level "
+                "matrix-value gathers 8 B/lane loads (taken as reported).  The matrix is read "
+                "once per time level, not once per step."},
+        open(os.path.join(DST, "traffic_pc_tile_sweep.json"), "w"), indent=1)
+
+print(sorted(os.listdir(DST)))
