@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 namespace kkt {
 
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     // step coefficients live in LDS behind the two iterates: a global load inside the step loop
     // would be drained by every workgroup barrier (vmcnt(0)), a round trip per step
     double *scoef = X + 2 * (size_t)nkp;
+    double *dump = scoef + 3 * (size_t)(its > 1 ? its - 1 : 1);
     const void *coef_key = nullptr;
     int cur = 0;             // X + cur * nkp: the newest iterate; the other half: the one before
     unsigned epoch = A.epoch0;   // tags never repeat between the launches of one application
@@ -166,13 +168,15 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                 if (both) publish(ro, gr[sl], Xo[r], epoch);
             }
         }
-        const gu64_p gn = (gu64_p)A.gnew[epoch & 1], go = (gu64_p)A.gold[epoch & 1];
-        unsigned long long na[HPT], nb[HPT], oa[HPT], ob[HPT];
+        // a granule {lo, tag, hi, tag} is read back by ONE 16-byte sc1 load (half the requests of
+        // two 8-byte loads; a torn read shows as unequal tags and is simply read again)
+        u32x4 gn4[HPT], go4[HPT];
         bool want_o[HPT];
 #pragma unroll
         for (int h = 0; h < HPT; ++h) {
             want_o[h] = both && hl[h] >= 0 && hl[h] < nk1;
-            na[h] = nb[h] = oa[h] = ob[h] = 0ull;       // tag 0 never matches a hand-off number
+            gn4[h] = u32x4{0u, 0u, 0u, 0u};         // tag 0 never matches a hand-off number
+            go4[h] = u32x4{0u, 0u, 0u, 0u};
         }
         // a poll samples memory about half a round trip after it is issued; the neighbours'
         // granules, stored at about the same time as this tile's, take about one: polling at
@@ -180,27 +184,20 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
         for (int i = 0; i < A.poll_delay; ++i) __builtin_amdgcn_s_sleep(1);
         unsigned spins = 0;
         while (true) {
+            asm volatile("" ::: "memory");   // the loads below are re-issued every round
             bool ok = true;
             // only what has not arrived yet is requested again
 #pragma unroll
             for (int h = 0; h < HPT; ++h) {
-                if (hl[h] >= 0 && ((unsigned)(na[h] >> 32) != epoch || (unsigned)(nb[h] >> 32) != epoch)) {
-                    const gu64_p g = gn + 2 * (size_t)hg[h];
-                    na[h] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    nb[h] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (want_o[h] && ((unsigned)(oa[h] >> 32) != epoch || (unsigned)(ob[h] >> 32) != epoch)) {
-                    const gu64_p g = go + 2 * (size_t)hg[h];
-                    oa[h] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ob[h] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                if (hl[h] >= 0 && (gn4[h].y != epoch || gn4[h].w != epoch))
+                    gn4[h] = __builtin_amdgcn_raw_buffer_load_b128(rn, hg[h] * 16, 0, 16 /* sc1 */);
+                if (want_o[h] && (go4[h].y != epoch || go4[h].w != epoch))
+                    go4[h] = __builtin_amdgcn_raw_buffer_load_b128(ro, hg[h] * 16, 0, 16 /* sc1 */);
             }
 #pragma unroll
             for (int h = 0; h < HPT; ++h) {
-                if (hl[h] >= 0)
-                    ok &= (unsigned)(na[h] >> 32) == epoch && (unsigned)(nb[h] >> 32) == epoch;
-                if (want_o[h])
-                    ok &= (unsigned)(oa[h] >> 32) == epoch && (unsigned)(ob[h] >> 32) == epoch;
+                if (hl[h] >= 0) ok &= gn4[h].y == epoch && gn4[h].w == epoch;
+                if (want_o[h]) ok &= go4[h].y == epoch && go4[h].w == epoch;
             }
             if (ok || dead) break;
             if (++spins >= TILE_SPIN_LIMIT) {
@@ -211,18 +208,16 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                 if (atomicCAS(A.err + 1, 0u, 1u) == 0u) {
 #pragma unroll
                     for (int h = 0; h < HPT; ++h)
-                        if (hl[h] >= 0 && ((unsigned)(na[h] >> 32) != epoch ||
-                                           (unsigned)(nb[h] >> 32) != epoch ||
-                                           (want_o[h] && ((unsigned)(oa[h] >> 32) != epoch ||
-                                                          (unsigned)(ob[h] >> 32) != epoch)))) {
+                        if (hl[h] >= 0 && (gn4[h].y != epoch || gn4[h].w != epoch ||
+                                           (want_o[h] && (go4[h].y != epoch || go4[h].w != epoch)))) {
                             A.err[8] = (unsigned)tile;
                             A.err[9] = epoch;
                             A.err[10] = (unsigned)hl[h];
                             A.err[11] = (unsigned)hg[h];
-                            A.err[12] = (unsigned)(na[h] >> 32);
-                            A.err[13] = (unsigned)(nb[h] >> 32);
-                            A.err[14] = (unsigned)(oa[h] >> 32);
-                            A.err[15] = (unsigned)(ob[h] >> 32);
+                            A.err[12] = gn4[h].y;
+                            A.err[13] = gn4[h].w;
+                            A.err[14] = go4[h].y;
+                            A.err[15] = go4[h].w;
                             A.err[16] = both ? 1u : 0u;
                         }
                 }
@@ -234,10 +229,10 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
         for (int h = 0; h < HPT; ++h) {
             if (hl[h] >= 0)
                 Xc[hl[h]] = __longlong_as_double(
-                    (long long)((na[h] & 0xffffffffull) | (nb[h] << 32)));
+                    (long long)((unsigned long long)gn4[h].x | ((unsigned long long)gn4[h].z << 32)));
             if (want_o[h])
                 Xo[hl[h]] = __longlong_as_double(
-                    (long long)((oa[h] & 0xffffffffull) | (ob[h] << 32)));
+                    (long long)((unsigned long long)go4[h].x | ((unsigned long long)go4[h].z << 32)));
         }
         // a wave that leaves this barrier knows every wave of the workgroup has finished reading
         // the granules of this epoch; only then may anyone publish the next one
@@ -378,13 +373,19 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                 for (int sl = 0; sl < RPT; ++sl) acc[sl] = 0.0;
                 if constexpr (PRE) {
                     if (have_u) {
+                        // all gathers in flight before the first fma (the chains of the slots
+                        // then run side by side instead of one LDS round trip per entry)
+                        double xu[PR][PW];
 #pragma unroll
-                        for (int sl = 0; sl < RPT; ++sl) {
-                            if (sl * T + (tid & ~63) >= nk1) continue;
+                        for (int sl = 0; sl < RPT; ++sl)
 #pragma unroll
-                            for (int k = 0; k < W; ++k)
-                                acc[sl] = __builtin_fma(un[sl][k], Xc[KKT_COL(sl, k)], acc[sl]);
-                        }
+                            for (int k = 0; k < W; ++k) xu[sl][k] = Xc[KKT_COL(sl, k)];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int k = 0; k < W; ++k)
+#pragma unroll
+                            for (int sl = 0; sl < RPT; ++sl)
+                                acc[sl] = __builtin_fma(un[sl][k], xu[sl][k], acc[sl]);
                     }
                 }
                 for (int t = have_u ? 1 : 0; t < L.n_upd; ++t) {
@@ -474,37 +475,92 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
             const double q1 = last ? post1 : 1.0, q2 = last ? post2 : 1.0;
             const bool has_old = s >= 3;
             double *Xc = X + cur * nkp, *Xo = X + (cur ^ 1) * nkp;
+            if constexpr (PACK) {
 #pragma unroll
-            for (int sl = 0; sl < RPT; ++sl) {
-                // wave-uniform: none of this wave's 64 rows of the slot is live on the shrunken
-                // region (the step is bound by the LDS gathers of the whole workgroup)
-                if (sl * T + (tid & ~63) >= nv) continue;
-                const int r = sl * T + tid;
-                double acc = 0.0;
+                for (int sl = 0; sl < RPT; ++sl) {
+                    // wave-uniform: none of this wave's 64 rows of the slot is live on the
+                    // shrunken region
+                    if (sl * T + (tid & ~63) >= nv) continue;
+                    const int r = sl * T + tid;
+                    double acc = 0.0;
 #pragma unroll
-                for (int k0 = 0; k0 < W; k0 += CH) {
-                    // (wide rows: a bounded number of gathers in flight, or the registers of the
-                    // matrix values spill)
-                    double xv[CH];
+                    for (int k0 = 0; k0 < W; k0 += CH) {
+                        // (wide rows: a bounded number of gathers in flight, or the registers of
+                        // the matrix values spill)
+                        double xv[CH];
 #pragma unroll
-                    for (int k = 0; k < CH; ++k)
-                        if (k0 + k < W) xv[k] = Xc[KKT_COL(sl, k0 + k)];
+                        for (int k = 0; k < CH; ++k)
+                            if (k0 + k < W) xv[k] = Xc[KKT_COL(sl, k0 + k)];
 #pragma unroll
-                    for (int k = 0; k < CH; ++k)
-                        if (k0 + k < W) acc = __builtin_fma(v[sl][k0 + k], xv[k], acc);
-                    if constexpr (PACK) __builtin_amdgcn_sched_barrier(0);
-                }
-                if (r < nv) {
-                    const double e0 = Xo[r], e1 = Xc[r];
-                    double out = 0.0;
-                    if (!msk[sl]) {
-                        double t = has_old ? cf1 * e0 : 0.0;
-                        t += cf2 * e1;
-                        t += cf3 * (dinv[sl] * (b[sl] - acc));
-                        out = q2 * (q1 * t);
+                        for (int k = 0; k < CH; ++k)
+                            if (k0 + k < W) acc = __builtin_fma(v[sl][k0 + k], xv[k], acc);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    Xo[r] = out;
+                    if (r < nv) {
+                        const double e0 = Xo[r], e1 = Xc[r];
+                        double out = 0.0;
+                        if (!msk[sl]) {
+                            double t = has_old ? cf1 * e0 : 0.0;
+                            t += cf2 * e1;
+                            t += cf3 * (dinv[sl] * (b[sl] - acc));
+                            out = q2 * (q1 * t);
+                        }
+                        Xo[r] = out;
+                    }
                 }
+            } else {
+                // Narrow rows: a step is a latency chain (gather, W dependent fmas, epilogue,
+                // store, barrier), not a throughput problem -- the slots of a thread run side by
+                // side: every gather of every live slot is issued before the first fma.  Live
+                // slots are a prefix (rows of a slot lie behind those of the one before); a wave
+                // none of whose 64 rows of a slot is live on the shrunken region skips the slot.
+                int nl = 0;
+                long long keep[RPT];
+#pragma unroll
+                for (int sl = 0; sl < RPT; ++sl) {
+                    if (sl * T + (tid & ~63) < nv) nl = sl + 1;
+                    keep[sl] = msk[sl] ? 0ll : -1ll;
+                    asm volatile("" : "+v"(keep[sl]));
+                }
+                auto body = [&](auto NLc) {
+                    constexpr int NL = decltype(NLc)::value;
+                    double xv[NL][W], e0[NL], e1[NL], acc[NL];
+#pragma unroll
+                    for (int sl = 0; sl < NL; ++sl) {
+#pragma unroll
+                        for (int k = 0; k < W; ++k) xv[sl][k] = Xc[KKT_COL(sl, k)];
+                        const int r = sl * T + tid;
+                        e0[sl] = Xo[r];
+                        e1[sl] = Xc[r];
+                        acc[sl] = 0.0;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < W; ++k)
+#pragma unroll
+                        for (int sl = 0; sl < NL; ++sl)
+                            acc[sl] = __builtin_fma(v[sl][k], xv[sl][k], acc[sl]);
+#pragma unroll
+                    for (int sl = 0; sl < NL; ++sl) {
+                        const int r = sl * T + tid;
+                        // (boundary rows: a bit mask, not a branch or a select the compiler
+                        // turns into one -- a branch per slot would put the chains of the slots
+                        // one behind the other again)
+                        double t = has_old ? cf1 * e0[sl] : 0.0;
+                        t += cf2 * e1[sl];
+                        t += cf3 * (dinv[sl] * (b[sl] - acc[sl]));
+                        const double out = __longlong_as_double(
+                            __double_as_longlong(q2 * (q1 * t)) & keep[sl]);
+                        // rows behind the live region store into a dump slot: an unconditional
+                        // store keeps the compiler from sinking the chain into a branch per slot
+                        *(r < nv ? Xo + r : dump) = out;
+                    }
+                };
+                if (nl == 1) body(std::integral_constant<int, 1>{});
+                if constexpr (RPT >= 2)
+                    if (nl == 2) body(std::integral_constant<int, 2>{});
+                if constexpr (RPT >= 3)
+                    if (nl == 3) body(std::integral_constant<int, 3>{});
             }
             if (s < its) {
                 const int crn = cr - 1 == 0 ? depth : cr - 1;
@@ -573,7 +629,7 @@ static tile_fn pick_tile(int W, int rpt, int threads) {
 bool tile_sweep_fuses_update(int W) { return W <= 9; }
 
 size_t tile_sweep_lds_bytes(int nk_pad, int its) {
-    return (2 * (size_t)nk_pad + 3 * (size_t)std::max(1, its - 1)) * sizeof(double);
+    return (2 * (size_t)nk_pad + 3 * (size_t)std::max(1, its - 1) + 1) * sizeof(double);
 }
 
 bool tile_sweep_available(int W, int rpt, int threads) {
