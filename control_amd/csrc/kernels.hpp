@@ -103,7 +103,8 @@ struct TileCoef { double c1, c2, c3; };
 // One time level of a sweep: optional update b = ca * (sum_t U_t x_prev) + cy * bin on the
 // boundary-masked rows, then `its` Jacobi-Chebyshev steps with the matrix `vals` on b, result in
 // `out` (control.py:2263-2295 / 2375-2406: "b_i += M u_{i-1}; solve").
-struct TileLevel {
+// (128 bytes, aligned: the two scalar-cache lines of a level hold one level only)
+struct alignas(128) TileLevel {
     const double *vals;        // SELL values of the level's matrix F_i
     const double *dinv;        // its Jacobi diagonal, inverted (1 on boundary rows)
     const double *bin;         // right-hand side before the update

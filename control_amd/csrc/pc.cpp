@@ -300,13 +300,13 @@ bool SchurPC::prepare_tiles() {
     const uint8_t *hm = hmask.empty() ? nullptr : hmask.data();
     if (tw) {
         threads = 64 * std::max(1, std::min(16, std::atoi(tw)));
-        if (!build_tile_plan(P, ntiles, depth, threads, threads > 512 ? 1 : 3, tile_plan_, hm))
+        if (!build_tile_plan(P, ntiles, depth, threads, threads > 512 ? 1 : 3, tile_plan_, hm, schur_its_))
             return false;
     } else {
         TilePlan big;
-        const bool ok_big = build_tile_plan(P, ntiles, depth, 1024, 1, big, hm) &&
+        const bool ok_big = build_tile_plan(P, ntiles, depth, 1024, 1, big, hm, schur_its_) &&
                             tile_sweep_available(big.W, big.rpt, 1024);
-        const bool ok_small = build_tile_plan(P, ntiles, depth, 512, 3, tile_plan_, hm) &&
+        const bool ok_small = build_tile_plan(P, ntiles, depth, 512, 3, tile_plan_, hm, schur_its_) &&
                               tile_sweep_available(tile_plan_.W, tile_plan_.rpt, 512);
         if (!ok_big && !ok_small) return false;
         if (ok_big && (!ok_small || big.model_us <= tile_plan_.model_us)) tile_plan_ = big;

@@ -54,6 +54,23 @@ __device__ __forceinline__ void publish(const __amdgpu_buffer_rsrc_t rs, int gro
     __builtin_amdgcn_raw_buffer_store_b128(g, rs, grow * 16, 0, 16 /* sc1 */);
 }
 
+// the fields of a level that are needed before the level begins (its operands are requested
+// under the last steps of the level before), by value
+struct LevEarly {
+    const double *vals, *dinv, *bin, *upd0;
+    int32_t n_upd, prev_in_lds;
+};
+__device__ __forceinline__ LevEarly read_early(const TileLevel *p) {
+    LevEarly f;
+    f.vals = p->vals;
+    f.dinv = p->dinv;
+    f.bin = p->bin;
+    f.upd0 = p->upd_vals[0];
+    f.n_upd = p->n_upd;
+    f.prev_in_lds = p->prev_in_lds;
+    return f;
+}
+
 template <int W, int RPT, int TMAX, bool UPD>
 __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     const TileArgs A, const TileLevel *__restrict__ levels, const int32_t *__restrict__ n_all,
@@ -63,11 +80,13 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     extern __shared__ double X[];
     __shared__ int sn[TILE_DEPTH_MAX + 1];
     __shared__ int sdead;
+    __shared__ unsigned long long sstat[8];
     const int T = blockDim.x, tid = threadIdx.x, tile = blockIdx.x;
     const int nkp = A.nk_pad, depth = A.depth, its = A.its;
     const int32_t *nt = n_all + (size_t)tile * (TILE_DEPTH_MAX + 1);
     const int n0 = nt[0], nk = nt[depth], nk1 = nt[depth - 1];
     if (tid <= TILE_DEPTH_MAX) sn[tid] = nt[tid];
+    if (tid < 8) sstat[tid] = 0ull;
     if (tid == 0) {
         sdead = 0;
         // the zero slot: what columns of boundary rows read (their iterates are exactly 0)
@@ -141,19 +160,36 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     unsigned long long *stat = reinterpret_cast<unsigned long long *>(A.err + 64) + (size_t)tile * 8;
     const bool stamps = A.stamps != 0;
     unsigned long long t_mark = stamps ? wall_clock64() : 0ull;
+    // (summed in LDS and written out once at the end: a read-modify-write of memory per stamp is
+    // a round trip that lands in the NEXT interval)
     auto lap = [&](int slot, unsigned long long count) {
         if (!stamps) return;
         const unsigned long long now = wall_clock64();
         if (tid == 0) {
-            stat[slot] += now - t_mark;
-            stat[slot + 3] += count;
+            sstat[slot] += now - t_mark;
+            sstat[slot + 3] += count;
         }
         t_mark = now;
     };
 
     // publish the own rows of the newest (and the previous) iterate, re-gather the rings
+    // The fields of a level are uniform values behind scalar loads, and the first reader of a
+    // line waits for it (1-2 us per dependent batch, every workgroup at the same moment; measured:
+    // 2.8 us of a level's first step).  lgkmcnt is shared with LDS, so the wait cannot be pushed
+    // past the next LDS barrier -- but a hand-off waits for memory anyway: what the NEXT level
+    // needs early is read at the start of the current level's first hand-off, one field from
+    // each of the two 64-byte lines of its struct, which the level's own reads then find cached.
+    static_assert(sizeof(TileLevel) == 128, "two scalar-cache lines per level");
+    LevEarly Nf{};
+    bool nf_valid = false;
+    const TileLevel *nf_want = nullptr;
     auto handoff = [&](const bool both) {
         lap(1, 0);
+        if (nf_want != nullptr) {
+            Nf = read_early(nf_want);
+            nf_want = nullptr;
+            nf_valid = true;
+        }
         ++epoch;
         double *Xc = X + cur * nkp, *Xo = X + (cur ^ 1) * nkp;
         const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(
@@ -238,7 +274,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
         // the granules of this epoch; only then may anyone publish the next one
         lds_barrier();
         dead = sdead != 0;
-        if (stamps && tid == 0) stat[6] += spins;
+        if (stamps && tid == 0) sstat[6] += spins;
         lap(0, 1);
     };
 
@@ -248,7 +284,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     // ends level l, so that the HBM fetch (every tile asks for its slice of the next matrix at
     // the same moment) runs under the hand-off's wait instead of after it.
     double dinv[RPT], b[RPT];
-    auto load_level = [&](const TileLevel &L) {
+    auto load_level = [&](const LevEarly &L) {
         if ((const void *)L.vals != vals_key) {
             vals_key = (const void *)L.vals;
             const gcd_p vp = (gcd_p)L.vals;
@@ -274,18 +310,39 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
             b[sl] = gr[sl] >= 0 ? bp[gr[sl]] : 0.0;
         }
     };
-    if (A.nlevels > 0) load_level(levels[0]);
+    if (A.nlevels > 0) load_level(read_early(&levels[0]));
 
     // Narrow rows leave registers for the NEXT level's operands (its matrix, the matrix of its
     // update, diagonal, right-hand side): they are requested when the last round of local steps
     // of a level begins and land under those steps.  Requested at the level's end they cost an
     // HBM round trip per level twice over -- once in front of the hand-off's polls (loads return
     // in order), once in front of the update (measured: 3 us of level prologue in mode G).
+    // Variants without that room (1 024 threads: 128 registers) still keep the values of the next
+    // update's matrix out of the level's first step: they are requested together with the next
+    // matrix in front of the hand-off that ends the level (PRE_U).
     constexpr bool PRE = UPD && W * RPT <= 14 && TMAX <= 512;
+    constexpr bool PRE_U = UPD && !PRE && W * RPT <= 7;
     constexpr int PR = PRE ? RPT : 1, PW = PRE ? W : 1;
-    double vn[PR][PW], un[PR][PW], dn[PR], bn[PR];
-    bool pre_v = false, pre_u = false, pre_issued = false;
-    auto prefetch_level = [&](const TileLevel &N) {
+    constexpr int UR = (PRE || PRE_U) ? RPT : 1, UW = (PRE || PRE_U) ? W : 1;
+    double vn[PR][PW], un[UR][UW], dn[PR], bn[PR];
+    bool pre_v = false, pre_u = false, pre_issued = false, un_loaded = false;
+    auto load_un = [&](const LevEarly &N) {
+        if constexpr (PRE || PRE_U) {
+            pre_u = N.n_upd > 0;
+            if (pre_u) {
+                const gcd_p up = (gcd_p)N.upd0;
+#pragma unroll
+                for (int sl = 0; sl < RPT; ++sl)
+#pragma unroll
+                    for (int k = 0; k < W; ++k) {
+                        const int gp = KKT_GP(sl, k);
+                        un[sl][k] = (gr[sl] >= 0 && gp >= 0) ? up[gp] : 0.0;
+                    }
+            }
+            un_loaded = true;
+        }
+    };
+    auto prefetch_level = [&](const LevEarly &N) {
         if constexpr (PRE) {
             pre_issued = true;
             pre_v = (const void *)N.vals != vals_key;
@@ -299,17 +356,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                         vn[sl][k] = gp >= 0 ? vp[gp] : 0.0;
                     }
             }
-            pre_u = N.n_upd > 0;
-            if (pre_u) {
-                const gcd_p up = (gcd_p)N.upd_vals[0];
-#pragma unroll
-                for (int sl = 0; sl < RPT; ++sl)
-#pragma unroll
-                    for (int k = 0; k < W; ++k) {
-                        const int gp = KKT_GP(sl, k);
-                        un[sl][k] = (gr[sl] >= 0 && gp >= 0) ? up[gp] : 0.0;
-                    }
-            }
+            load_un(N);
             const gcd_p dp = (gcd_p)N.dinv, bp = (gcd_p)N.bin;
 #pragma unroll
             for (int sl = 0; sl < RPT; ++sl) {
@@ -318,7 +365,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
             }
         }
     };
-    auto adopt_level = [&](const TileLevel &N) {
+    auto adopt_level = [&](const LevEarly &N) {
         if constexpr (PRE) {
             if (pre_v) {
                 vals_key = (const void *)N.vals;
@@ -337,8 +384,11 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
 
     for (int lev = 0; lev < A.nlevels; ++lev) {
         const TileLevel &L = levels[lev];
-        const bool have_u = PRE && pre_issued && pre_u;   // un holds the values of upd_vals[0]
+        nf_valid = false;
+        nf_want = lev + 1 < A.nlevels ? &levels[lev + 1] : nullptr;
+        const bool have_u = (PRE || PRE_U) && un_loaded && pre_u;   // un = values of upd_vals[0]
         pre_issued = false;
+        un_loaded = false;
         if ((const void *)L.coef != coef_key) {
             coef_key = (const void *)L.coef;
             const gcd_p cp = (gcd_p)(const double *)L.coef;
@@ -356,6 +406,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
             asm volatile("" : "+v"(dinv[sl]));
             asm volatile("" : "+v"(b[sl]));
         }
+        if (stamps && tid == 0) sstat[7] += wall_clock64() - t_mark;   // prologue up to the update
         const double post1 = L.post1, post2 = L.post2;
         int cr;
         {
@@ -371,11 +422,11 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                 double acc[RPT];
 #pragma unroll
                 for (int sl = 0; sl < RPT; ++sl) acc[sl] = 0.0;
-                if constexpr (PRE) {
+                if constexpr (PRE || PRE_U) {
                     if (have_u) {
                         // all gathers in flight before the first fma (the chains of the slots
                         // then run side by side instead of one LDS round trip per entry)
-                        double xu[PR][PW];
+                        double xu[UR][UW];
 #pragma unroll
                         for (int sl = 0; sl < RPT; ++sl)
 #pragma unroll
@@ -450,7 +501,12 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
             cur ^= 1;
         }
         const bool has_next = lev + 1 < A.nlevels;
-        if (PRE && has_next && its - 1 <= cr) prefetch_level(levels[lev + 1]);
+        if (PRE && has_next && its - 1 <= cr) {
+            Nf = read_early(&levels[lev + 1]);        // (a level without a hand-off of its own)
+            nf_want = nullptr;
+            nf_valid = true;
+            prefetch_level(Nf);
+        }
 #pragma unroll
         for (int sl = 0; sl < RPT; ++sl) {
             asm volatile("" : "+v"(dinv[sl]));
@@ -467,7 +523,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                 handoff(s >= 3);
                 cr = depth;
                 // the last round of the level: the next level's operands travel under it
-                if (PRE && has_next && its - s < depth) prefetch_level(levels[lev + 1]);
+                if (PRE && has_next && its - s < depth) prefetch_level(Nf);
             }
             const int nv = nv_next;
             const double cf1 = cn1, cf2 = cn2, cf3 = cn3;
@@ -584,13 +640,20 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                 if (r < n0) op[gr[sl]] = Xc[r];
             }
             if (lev + 1 < A.nlevels) {
-                const TileLevel &N = levels[lev + 1];
-                if (!(PRE && pre_issued)) load_level(N);
+                if (!nf_valid) Nf = read_early(&levels[lev + 1]);
+                nf_want = nullptr;
+                const LevEarly &N = Nf;
+                if (!(PRE && pre_issued)) {
+                    load_level(N);
+                    if constexpr (PRE_U) load_un(N);
+                }
                 if (N.n_upd > 0 && N.prev_in_lds) handoff(false);
                 if (PRE && pre_issued) adopt_level(N);
             }
         }
     }
+    if (stamps && tid == 0)
+        for (int i = 0; i < 8; ++i) stat[i] += sstat[i];
 }
 
 #undef KKT_COL

@@ -103,7 +103,7 @@ void TilePlan::release() {
 }
 
 bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int max_rpt,
-                     TilePlan &out, const uint8_t *mask) {
+                     TilePlan &out, const uint8_t *mask, int its) {
     if (P.nrows != P.ncols || ntiles < 1 || depth > TILE_MAX_DEPTH) return false;
     const bool auto_depth = depth <= 0;
     if (auto_depth) depth = TILE_MAX_DEPTH;
@@ -160,11 +160,13 @@ bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int m
             for (int j = depth + 1; j <= TILE_MAX_DEPTH; ++j) nt[j] = nt[depth];
         }
     }
-    // Modelled microseconds per dependent step: one hand-off per `d` steps plus the local steps
-    // (fitted to per-tile timings on MI355X, 256^2 P1, depths 2 .. 10, DESIGN.md section 6: a
-    // hand-off costs 1.5 us + 1.9 us per 1 000 granule pairs gathered -- the newest iterate on all
-    // rings, the previous one on all but the outermost --, a local step 0.30 us + 0.23 us per
-    // 1 000 rows computed; 1 024-thread workgroups: 1.15 + 2.4 and 0.37 + 0.06).
+    // Modelled microseconds per dependent step: one hand-off per `d` steps plus the local steps,
+    // fitted to per-tile timings on MI355X (256^2 P1, depths 4 .. 8, 16-byte granule polls;
+    // DESIGN.md section 6).  A hand-off costs a + b per 1 000 granule pairs gathered (the newest
+    // iterate on all rings, the previous one on all but the outermost), a local step c + e per
+    // 1 000 rows computed: 1 024-thread workgroups 1.68 + 1.32 and 0.34 + 0.12, 512-thread
+    // workgroups 1.5 + 1.5 and 0.38 + 0.16.  With the steps per level known, the hand-offs of a
+    // level are counted whole (ceil(its / d): 80 steps at depth 7 are 12 rounds, at depth 6: 14).
     auto model = [&](int d, double *us) -> bool {
         int64_t mk = 0, mr = 0, mh = 0, mo = 0;
         for (int t = 0; t < ntiles; ++t) {
@@ -178,13 +180,16 @@ bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int m
         while ((int64_t)(rp + 1) * threads < mh) ++rp;
         if (mk > 65535 || rp > max_rpt) return false;
         const bool big = threads > 512;
-        const double handoff = (big ? 1.15 : 1.5) + (big ? 2.4e-3 : 1.9e-3) * (double)(mh + mo);
-        const double step = big ? 0.37 + 0.06e-3 * (double)mr : 0.30 + 0.23e-3 * (double)mr;
-        *us = (handoff + d * step) / d;
+        const double handoff = (big ? 1.68 : 1.5) + (big ? 1.32e-3 : 1.5e-3) * (double)(mh + mo);
+        const double step = big ? 0.34 + 0.12e-3 * (double)mr : 0.38 + 0.16e-3 * (double)mr;
+        if (its > 0)
+            *us = ((double)((its + d - 1) / d) * handoff + its * step) / its;
+        else
+            *us = (handoff + d * step) / d;
         return true;
     };
     if (auto_depth) {
-        // the optimum is flat: the shallowest depth within 3 % of the best (fewer redundant rows,
+        // the optimum is flat: the shallowest depth within 1 % of the best (fewer redundant rows,
         // smaller rings) is taken
         double best = 1e300, per[TILE_MAX_DEPTH + 1];
         int n_ok = 0, best_d = 0;
@@ -194,7 +199,7 @@ bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int m
             n_ok = d;
         }
         for (int d = 1; d <= n_ok && !best_d; ++d)
-            if (per[d] <= 1.03 * best) best_d = d;
+            if (per[d] <= 1.01 * best) best_d = d;
         if (best_d == 0) return false;
         depth = best_d;
         out.depth = depth;

@@ -52,7 +52,8 @@ struct TilePlan {
 // `mask` (may be null): rows with mask[r] != 0 -- Dirichlet rows, whose iterates are exactly zero
 // and whose columns are zeroed in every matrix of a sweep -- belong to no tile and to no ring;
 // columns that point at them read the tile's permanent zero slot (local index nk_pad - 1).
+// `its` (0: unknown): dependent steps per level, for the depth model (hand-offs counted whole).
 bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int max_rpt,
-                     TilePlan &out, const uint8_t *mask = nullptr);
+                     TilePlan &out, const uint8_t *mask = nullptr, int its = 0);
 
 }  // namespace kkt

@@ -38,4 +38,5 @@ for name, col, cnt in (("hand-off", 0, 3), ("local step", 1, 4), ("level prologu
     v = d[:, col] * us / d[:, cnt]
     tot = d[:, col] * us / reps / 1e3
     print(f"{name:15s} us each: mean {v.mean():7.3f} min {v.min():7.3f} max {v.max():7.3f}   total ms/application: mean {tot.mean():6.2f} max {tot.max():6.2f}")
+print(f"level prologue up to the update (operands in registers): us each mean {(d[:,7]*us/d[:,5]).mean():.3f} max {(d[:,7]*us/d[:,5]).max():.3f}")
 print(f"poll rounds per hand-off: mean {(d[:,6]/d[:,3]).mean():.1f} max {(d[:,6]/d[:,3]).max():.1f}")
