@@ -22,7 +22,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["RcclComm", "CallbackComm", "PipeTransport", "GlooTransport", "make_comm",
+__all__ = ["RcclComm", "RcclOrGloo", "CallbackComm", "PipeTransport", "GlooTransport", "make_comm",
            "shard_range"]
 
 
@@ -195,10 +195,59 @@ class GlooTransport:
         return None if out is None else out.numpy()
 
 
+class RcclOrGloo(_CommBase):
+    """RCCL, checked when it is attached; if any rank could not bring it up (the ranks agree
+    over a gloo group of the launcher's rendezvous), every rank falls back to the host-staged
+    gloo transport and says so (``name``).  For launchers that must produce a measurement even
+    where RCCL does not start (``bench.py --gpus N``); a library user picks one transport."""
+
+    def __init__(self, rank, world):
+        super().__init__(rank, world)
+        self._rccl = RcclComm(rank, world)
+        self._gloo = None
+        self.name = "rccl"
+
+    def _agree(self, ok):
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    def attach(self, system):
+        if self._gloo is not None:
+            self._gloo.attach(system)
+            return
+        why = ""
+        try:
+            self._rccl.attach(system)
+            v = C.c_double(float(self.rank))
+            system._ck(system._lib.kkt_comm_max(system.handle, C.byref(v)))
+            ok = v.value == float(self.world - 1)
+            if not ok:
+                why = f"max over ranks gave {v.value}"
+        except Exception as e:                      # noqa: BLE001 -- any failure means fallback
+            ok, why = False, f"{type(e).__name__}: {e}"
+        if self._agree(ok):
+            return
+        import sys
+        print(f"[kkt] rank {self.rank}: RCCL transport not usable ({why or 'another rank failed'}); "
+              "falling back to the host-staged gloo transport", file=sys.stderr, flush=True)
+        tr = GlooTransport(self.rank, self.world)
+        self._gloo = CallbackComm(self.rank, self.world, tr.allreduce, tr.sendrecv)
+        self._gloo.attach(system)
+        self.name = "gloo (host-staged; RCCL did not start)"
+
+
 def make_comm(rank, world, local_rank=0):
-    """Transport for ``bench.py`` under ``torch.distributed.run``: RCCL over xGMI, or the
-    gloo rehearsal transport when ``KKT_TRANSPORT=gloo``."""
+    """Transport for ``bench.py`` under ``torch.distributed.run``: RCCL over xGMI (with the
+    gloo transport as the fallback if RCCL does not start), or the gloo rehearsal transport
+    outright when ``KKT_TRANSPORT=gloo``."""
     if os.environ.get("KKT_TRANSPORT", "rccl") == "gloo":
         tr = GlooTransport(rank, world)
-        return CallbackComm(rank, world, tr.allreduce, tr.sendrecv)
-    return RcclComm(rank, world)
+        c = CallbackComm(rank, world, tr.allreduce, tr.sendrecv)
+        c.name = "gloo"
+        return c
+    return RcclOrGloo(rank, world)
