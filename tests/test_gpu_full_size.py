@@ -109,6 +109,28 @@ def test_config2_solve_true_residual(cfg2):
     assert common.rel_err(u, xs) < 1e-4          # 1.1e-5 measured at a 2e-8 residual
 
 
+def test_config2_crank_nicolson_operator_and_preconditioner():
+    """The same system with the Crank-Nicolson scheme (test_control.py:1936-2040 shape; the
+    time transforms T_1, T_2 around the blocks, control.py:1995-2189 for the preconditioner) as
+    `bench.py --scheme CN` times it: operator 1e-13 and one preconditioner application 1e-9
+    against the oracle, tile sweep programs bit-identical to plain launches."""
+    t0 = time.time()
+    p = common.heat_problem(n=256, n_t=64, beta=1.0e-4, CN=True)
+    schur = (140, 7.0e-4, 2.1)
+    g = common.gpu_system(p, share_values=False)
+    osys = common.oracle_system(p)
+    x = common.rng_vector(osys.N, common.SEED)
+    assert common.rel_err(g.mult(x), osys.mult(x)) < 1e-13
+    got = g.pc_apply(x, common.gpu_pc(p, CFG2_MASS, schur))
+    _log("CN gpu operator + pc_apply", t0)
+    ref = osys.pc_apply(common.oracle_pc(p, CFG2_MASS, schur), x)
+    _log("+ numpy oracle", t0)
+    assert common.rel_err(got, ref) < 1e-9
+    g2 = common.gpu_system(p, share_values=False, options={"persistent": "0"})
+    assert np.array_equal(got, g2.pc_apply(x, common.gpu_pc(p, CFG2_MASS, schur)))
+    _log("+ plain launches", t0)
+
+
 # ------------------------------------------------------------------ configs[2]
 CFG3_SPECS = dict(mass=(20, 0.3924, 2.0598), mp=(20, 0.5, 2.0), schur=(40, 0.002, 2.25),
                   kp=(40, 0.002, 2.1))                               # bench.py --workload stokes2d
