@@ -136,7 +136,7 @@ struct TileArgs {
 bool tile_sweep_available(int W, int rpt, int threads);
 // whether the variant for this shape computes the level update b -= U u_prev itself (narrow
 // rows); wide rows (3-D P1) have no registers for it: the update stays a launch of its own
-bool tile_sweep_fuses_update(int W);
+bool tile_sweep_fuses_update(int W, int max_terms);   // update terms of any level of the run
 size_t tile_sweep_lds_bytes(int nk_pad, int its);
 // workgroups of `threads` that are certainly co-resident (one per CU)
 int tile_sweep_max_tiles(int W, int rpt, int threads, size_t lds_bytes);

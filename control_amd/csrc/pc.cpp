@@ -378,9 +378,10 @@ bool SchurPC::fuse_tile_run(size_t k, size_t e, std::vector<PcStep> &out) {
         levels.push_back(L);
     }
     const int per_launch = its / std::max(1, tile_plan_.depth) + 2;   // hand-offs of a level, at most
-    auto tile_step = [&](const TileLevel *lv, int n, int nphases) {
+    auto tile_step = [&](const TileLevel *lv, int n, int nphases, bool fused) {
         PcStep s;
         s.kind = PcStep::TILE;
+        s.fused = fused;
         s.d_levels = dev_upload(lv, (size_t)n);
         s.nlevels = n;
         s.its = its;
@@ -391,9 +392,11 @@ bool SchurPC::fuse_tile_run(size_t k, size_t e, std::vector<PcStep> &out) {
         tile_epoch_cursor_ += (uint32_t)(n * per_launch);
         out.push_back(s);
     };
-    if (tile_sweep_fuses_update(tile_plan_.W)) {
+    int max_terms = 0;
+    for (const TileLevel &L : levels) max_terms = std::max(max_terms, (int)L.n_upd);
+    if (tile_sweep_fuses_update(tile_plan_.W, max_terms)) {
         for (size_t q = k; q < e; ++q) (void)hipFree(steps_[q].rows.d_ops);
-        tile_step(levels.data(), (int)levels.size(), (int)(e - k));
+        tile_step(levels.data(), (int)levels.size(), (int)(e - k), true);
         return true;
     }
     // Wide rows: the kernel has no registers for the level update.  It stays the plain launch it
@@ -413,7 +416,7 @@ bool SchurPC::fuse_tile_run(size_t k, size_t e, std::vector<PcStep> &out) {
             L.bout = nullptr;
         }
         for (size_t q = first_cheb; q < lv.last; ++q) (void)hipFree(steps_[q].rows.d_ops);
-        tile_step(&L, 1, (int)(lv.last - first_cheb));
+        tile_step(&L, 1, (int)(lv.last - first_cheb), false);
     }
     return true;
 }
@@ -1284,7 +1287,7 @@ void SchurPC::replay(size_t first, size_t last) {
                 a.err = d_err_;
                 a.epoch0 = s.epoch0;
                 a.clear = s.clear ? 1 : 0;
-                a.fused_update = tile_sweep_fuses_update(tp.W) ? 1 : 0;
+                a.fused_update = s.fused ? 1 : 0;
                 a.stamps = S_.opt("stamps") != nullptr;
                 {
                     const char *dd = S_.opt("debug_drop_handoff");

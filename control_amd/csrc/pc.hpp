@@ -40,6 +40,7 @@ struct PcStep {
     TileLevel *d_levels = nullptr;  // TILE: nlevels time levels of `its` steps each
     int nlevels = 0, its = 0;
     uint32_t epoch0 = 0;            // TILE: first hand-off tag of this launch minus one
+    bool fused = true;              // TILE: kernel variant with the level update
     bool clear = false;             // TILE: zero the granule buffers first
 };
 

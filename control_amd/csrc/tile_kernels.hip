@@ -284,25 +284,36 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     // ends level l, so that the HBM fetch (every tile asks for its slice of the next matrix at
     // the same moment) runs under the hand-off's wait instead of after it.
     double dinv[RPT], b[RPT];
-    auto load_level = [&](const LevEarly &L) {
-        if ((const void *)L.vals != vals_key) {
-            vals_key = (const void *)L.vals;
-            const gcd_p vp = (gcd_p)L.vals;
+    // (wide rows: the positions of all slots first, then the values -- two dependent round trips
+    // instead of two per chunk of five entries)
+    auto load_vals = [&](const double *ptr, const bool update_matrix) {
+        vals_key = (const void *)ptr;
+        const gcd_p vp = (gcd_p)ptr;
+        if constexpr (PACK) {
+            int gp[RPT][W];
 #pragma unroll
-            for (int sl = 0; sl < RPT; ++sl) {
+            for (int sl = 0; sl < RPT; ++sl)
 #pragma unroll
-                for (int k0 = 0; k0 < W; k0 += CH) {
-                    int gp[CH];
+                for (int k = 0; k < W; ++k) gp[sl][k] = KKT_GP(sl, k);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int k = 0; k < CH; ++k)
-                        if (k0 + k < W) gp[k] = KKT_GP(sl, k0 + k);
+            for (int sl = 0; sl < RPT; ++sl)
 #pragma unroll
-                    for (int k = 0; k < CH; ++k)
-                        if (k0 + k < W) v[sl][k0 + k] = gp[k] >= 0 ? vp[gp[k]] : 0.0;
-                    if constexpr (PACK) __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < W; ++k)
+                    v[sl][k] = (gp[sl][k] >= 0 && (!update_matrix || gr[sl] >= 0))
+                                   ? vp[gp[sl][k]] : 0.0;
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+            for (int sl = 0; sl < RPT; ++sl)
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    const int gp = KKT_GP(sl, k);
+                    v[sl][k] = (gp >= 0 && (!update_matrix || gr[sl] >= 0)) ? vp[gp] : 0.0;
                 }
-            }
         }
+    };
+    auto load_db = [&](const LevEarly &L) {
         const gcd_p dp = (gcd_p)L.dinv, bp = (gcd_p)L.bin;
 #pragma unroll
         for (int sl = 0; sl < RPT; ++sl) {
@@ -310,7 +321,28 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
             b[sl] = gr[sl] >= 0 ? bp[gr[sl]] : 0.0;
         }
     };
-    if (A.nlevels > 0) load_level(read_early(&levels[0]));
+    auto load_level = [&](const LevEarly &L) {
+        if ((const void *)L.vals != vals_key) load_vals(L.vals, false);
+        load_db(L);
+    };
+    // Wide rows with the level update in the kernel (SEQ): there are no registers for a second
+    // matrix, so the update's matrix passes through the registers of the level matrix -- it is
+    // requested in front of the hand-off that ends a level (the old matrix is dead by then),
+    // multiplied after it, and only then is the new level's own matrix requested (one exposed
+    // fetch per level instead of a kernel boundary, a plain update launch and the per-launch
+    // structure loads).
+    constexpr bool SEQ = PACK && UPD;
+    bool v_is_u = false;
+    if (A.nlevels > 0) {
+        const LevEarly L0 = read_early(&levels[0]);
+        if (SEQ && L0.n_upd > 0) {
+            load_vals(L0.upd0, true);
+            load_db(L0);
+            v_is_u = true;
+        } else {
+            load_level(L0);
+        }
+    }
 
     // Narrow rows leave registers for the NEXT level's operands (its matrix, the matrix of its
     // update, diagonal, right-hand side): they are requested when the last round of local steps
@@ -387,8 +419,10 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
         nf_valid = false;
         nf_want = lev + 1 < A.nlevels ? &levels[lev + 1] : nullptr;
         const bool have_u = (PRE || PRE_U) && un_loaded && pre_u;   // un = values of upd_vals[0]
+        const bool use_v = SEQ && v_is_u;                            // v = values of upd_vals[0]
         pre_issued = false;
         un_loaded = false;
+        v_is_u = false;
         if ((const void *)L.coef != coef_key) {
             coef_key = (const void *)L.coef;
             const gcd_p cp = (gcd_p)(const double *)L.coef;
@@ -439,6 +473,29 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                                 acc[sl] = __builtin_fma(un[sl][k], xu[sl][k], acc[sl]);
                     }
                 }
+                if constexpr (SEQ) {
+                    if (use_v) {
+#pragma unroll
+                        for (int sl = 0; sl < RPT; ++sl) {
+                            if (sl * T + (tid & ~63) >= nk1) continue;
+#pragma unroll
+                            for (int k0 = 0; k0 < W; k0 += CH) {
+                                double xv[CH];
+#pragma unroll
+                                for (int k = 0; k < CH; ++k)
+                                    if (k0 + k < W) xv[k] = Xc[KKT_COL(sl, k0 + k)];
+#pragma unroll
+                                for (int k = 0; k < CH; ++k)
+                                    if (k0 + k < W)
+                                        acc[sl] = __builtin_fma(v[sl][k0 + k], xv[k], acc[sl]);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+                }
+                // (SEQ: one update term, the host's condition for this variant -- with this
+                // loop compiled in, the two-slot variant spills 88 registers)
+                if constexpr (!SEQ)
                 for (int t = have_u ? 1 : 0; t < L.n_upd; ++t) {
                     const gcd_p up = (gcd_p)L.upd_vals[t];
 #pragma unroll
@@ -480,6 +537,10 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                     if (r < nk1) Xo[r] = out2;
                     if (r < n0 && bo != nullptr) bo[gr[sl]] = out;
                 }
+                if constexpr (SEQ) {
+                    // the level's own matrix, now that the update's has been used
+                    if ((const void *)L.vals != vals_key) load_vals(L.vals, false);
+                }
             } else {
                 // first step of a solve on a right-hand side that is already final
                 const bool last = its == 1;
@@ -509,6 +570,10 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
         }
 #pragma unroll
         for (int sl = 0; sl < RPT; ++sl) {
+            if constexpr (SEQ) {
+#pragma unroll
+                for (int k = 0; k < W; ++k) asm volatile("" : "+v"(v[sl][k]));
+            }
             asm volatile("" : "+v"(dinv[sl]));
             asm volatile("" : "+v"(b[sl]));
         }
@@ -644,8 +709,14 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                 nf_want = nullptr;
                 const LevEarly &N = Nf;
                 if (!(PRE && pre_issued)) {
-                    load_level(N);
-                    if constexpr (PRE_U) load_un(N);
+                    if (SEQ && N.n_upd > 0) {
+                        load_vals(N.upd0, true);
+                        load_db(N);
+                        v_is_u = true;
+                    } else {
+                        load_level(N);
+                        if constexpr (PRE_U) load_un(N);
+                    }
                 }
                 if (N.n_upd > 0 && N.prev_in_lds) handoff(false);
                 if (PRE && pre_issued) adopt_level(N);
@@ -665,7 +736,7 @@ typedef void (*tile_fn)(const TileArgs, const TileLevel *, const int32_t *, cons
 // (2-D P1) run 512 threads with up to three row slots or 1 024 with one, level update fused.
 // Wide rows (3-D P1: 15 entries, 30 registers of matrix values per row slot) run 512 threads with
 // two slots in the variant without the fused update (244 registers; with it 256 + 78 spilled).
-static tile_fn pick_tile(int W, int rpt, int threads) {
+static tile_fn pick_tile(int W, int rpt, int threads, bool fused = true) {
 #define KKT_T(w)                                                           \
     if (W == w) {                                                          \
         if (threads <= 512) {                                              \
@@ -680,16 +751,21 @@ static tile_fn pick_tile(int W, int rpt, int threads) {
     }
     KKT_T(5) KKT_T(7) KKT_T(9)
 #undef KKT_T
+    // Wide rows: with the level update (one term, its matrix passing through the registers of
+    // the level matrix) or without (the update stays a plain launch, one tile launch per level)
     if (W == 15 && threads <= 512) {
-        if (rpt == 1) return pc_tile_sweep<15, 1, 512, false>;
-        if (rpt == 2) return pc_tile_sweep<15, 2, 512, false>;
+        if (rpt == 1) return fused ? pc_tile_sweep<15, 1, 512, true> : pc_tile_sweep<15, 1, 512, false>;
+        if (rpt == 2) return fused ? pc_tile_sweep<15, 2, 512, true> : pc_tile_sweep<15, 2, 512, false>;
     }
     // P2 velocity blocks (9 or 19 entries per row, row-sorted storage): one row slot
-    if (W == 19 && threads <= 512 && rpt == 1) return pc_tile_sweep<19, 1, 512, false>;
+    if (W == 19 && threads <= 512 && rpt == 1)
+        return fused ? pc_tile_sweep<19, 1, 512, true> : pc_tile_sweep<19, 1, 512, false>;
     return nullptr;
 }
 
-bool tile_sweep_fuses_update(int W) { return W <= 9; }
+bool tile_sweep_fuses_update(int W, int max_terms) {
+    return W <= 9 || ((W == 15 || W == 19) && max_terms <= 1);
+}
 
 size_t tile_sweep_lds_bytes(int nk_pad, int its) {
     return (2 * (size_t)nk_pad + 3 * (size_t)std::max(1, its - 1) + 1) * sizeof(double);
@@ -701,17 +777,23 @@ bool tile_sweep_available(int W, int rpt, int threads) {
 }
 
 int tile_sweep_max_tiles(int W, int rpt, int threads, size_t lds_bytes) {
-    tile_fn f = pick_tile(W, rpt, threads);
-    int dev = 0, cus = 0, per_cu = 0;
-    if (!f || hipGetDevice(&dev) != hipSuccess) return 0;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (lds_bytes > 48 * 1024 &&
-        hipFuncSetAttribute((const void *)f, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds_bytes) != hipSuccess)
-        return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, threads, lds_bytes) != hipSuccess)
-        return 0;
-    return per_cu >= 1 ? cus : 0;   // one workgroup per CU
+    // both variants of a width (with / without the level update) must be resident
+    for (int fused = 0; fused < 2; ++fused) {
+        tile_fn f = pick_tile(W, rpt, threads, fused != 0);
+        int per_cu = 0;
+        if (!f) return 0;
+        if (lds_bytes > 48 * 1024 &&
+            hipFuncSetAttribute((const void *)f, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes) != hipSuccess)
+            return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, threads, lds_bytes) != hipSuccess)
+            return 0;
+        if (per_cu < 1) return 0;
+    }
+    return cus;   // one workgroup per CU
 }
 
 void launch_tile_sweep(hipStream_t s, const TileArgs &a, const TileLevel *d_levels,
@@ -726,7 +808,7 @@ void launch_tile_sweep(hipStream_t s, const TileArgs &a, const TileLevel *d_leve
             (void)hipMemsetAsync(a.gold[i], 0, granule_words * sizeof(unsigned long long), s);
         }
     const size_t lds = tile_sweep_lds_bytes(a.nk_pad, a.its);
-    hipLaunchKernelGGL(pick_tile(a.W, a.rpt, threads), dim3(ntiles), dim3(threads), lds, s, a, d_levels,
+    hipLaunchKernelGGL(pick_tile(a.W, a.rpt, threads, a.fused_update != 0), dim3(ntiles), dim3(threads), lds, s, a, d_levels,
                        d_n, d_grow, d_lcol, d_gpos, d_rowmask);
 }
 
