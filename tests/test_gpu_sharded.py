@@ -97,3 +97,26 @@ def test_rccl_transport_single_rank():
     v = C.c_double(3.25)
     assert lib.kkt_comm_max(h, C.byref(v)) == 0, lib.kkt_last_error(h)
     assert v.value == 3.25
+
+
+def test_bench_two_ranks_on_one_gpu_falls_back_to_gloo():
+    """``bench.py --gpus 2`` exactly as the driver launches it (torch.distributed.run, one process
+    per rank), both ranks on GPU 0: RCCL refuses two ranks on one device, the ranks agree to
+    fall back to the host-staged gloo transport (control_amd.dist.RcclOrGloo), the sharded solve
+    converges in the single-GPU iteration count and the line says what ran."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, KKT_DEVICE="0", PYTHONUNBUFFERED="1")
+    env.pop("KKT_TRANSPORT", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-config4", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=420)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 4
+    assert line["config"]["transport"].startswith("gloo"), line["config"]["transport"]
+    tts = line["config"]["time_to_solution"]
+    assert tts["converged"] and tts["iterations"] == 40      # as on one GPU (profiles/r02)
+    assert "RCCL transport not usable" in out.stderr
