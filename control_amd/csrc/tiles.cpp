@@ -253,9 +253,7 @@ bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int m
                 const size_t at = base + ((size_t)slot * W + k) * T + tid;
                 if (k < len) {
                     const int32_t c = P.h_indices[P.h_indptr[g] + k];
-                    // (timing experiment only, results wrong: every gather hits the own row)
-                    static const bool nogather = std::getenv("KKT_TILE_NOGATHER") != nullptr;
-                    out.lcol[at] = (uint16_t)(nogather ? r : (mask && mask[c]) ? out.nk_pad - 1 : lidx[c]);
+                    out.lcol[at] = (uint16_t)((mask && mask[c]) ? out.nk_pad - 1 : lidx[c]);
                     out.gpos[at] = (int32_t)P.sell_index(g, k);
                 } else {
                     out.lcol[at] = (uint16_t)(live ? r : 0);   // value 0: any valid index
