@@ -1297,7 +1297,7 @@ void SchurPC::replay(size_t first, size_t last) {
                     const char *pd = S_.opt("tile_poll_delay");
                     // s_sleep units before the first poll: ~0.7 us; ~1.4 us for the big rings of
                     // 3-D tiles (measured optima: 256^2 P1 24, 64^3 P1 48)
-                    a.poll_delay = pd ? std::atoi(pd) : (tp.max_halo > 800 ? 48 : 24);
+                    a.poll_delay = pd ? std::atoi(pd) : 24;
                 }
                 launch_tile_sweep(st, a, s.d_levels, tp.d_n, tp.d_grow, tp.d_lcol, tp.d_gpos, mask_,
                                   tp.ntiles, tp.threads, words);

@@ -183,7 +183,9 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     LevEarly Nf{};
     bool nf_valid = false;
     const TileLevel *nf_want = nullptr;
-    auto handoff = [&](const bool both) {
+    // `early`: the newest iterate's own rows went out from the step that computed them (the last
+    // step of the round), under that step's remaining work; only the previous iterate is left
+    auto handoff = [&](const bool both, const bool early = false) {
         lap(1, 0);
         if (nf_want != nullptr) {
             Nf = read_early(nf_want);
@@ -200,8 +202,9 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
         for (int sl = 0; sl < RPT; ++sl) {
             const int r = sl * T + tid;
             if (r < n0 && !(tile == 0 && A.debug_drop > 0 && (int)(epoch - A.epoch0) == A.debug_drop)) {
-                publish(rn, gr[sl], Xc[r], epoch);
-                if (both) publish(ro, gr[sl], Xo[r], epoch);
+                if (!early) publish(rn, gr[sl], Xc[r], epoch);
+                // (at depth 1 no ring row is ever computed: nobody reads the previous iterate)
+                if (both && depth > 1) publish(ro, gr[sl], Xo[r], epoch);
             }
         }
         // a granule {lo, tag, hi, tag} is read back by ONE 16-byte sc1 load (half the requests of
@@ -583,9 +586,11 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
         // the barrier's own wait instead of in front of the step's gathers)
         int nv_next = sn[(cr == 0 ? depth : cr) - 1];
         double cn1 = scoef[0], cn2 = scoef[1], cn3 = scoef[2];
+        bool early_done = false;   // the step before published the own rows already
         for (int s = 2; s <= its; ++s) {
             if (cr == 0) {
-                handoff(s >= 3);
+                handoff(s >= 3, early_done);
+                early_done = false;
                 cr = depth;
                 // the last round of the level: the next level's operands travel under it
                 if (PRE && has_next && its - s < depth) prefetch_level(Nf);
@@ -596,6 +601,15 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
             const double q1 = last ? post1 : 1.0, q2 = last ? post2 : 1.0;
             const bool has_old = s >= 3;
             double *Xc = X + cur * nkp, *Xo = X + (cur ^ 1) * nkp;
+            // a hand-off follows this step inside the level
+            // (wide rows only -- on narrow rows at depth 5-7 the stores in the step cost more
+            // than the hand-off gains: 0.45 -> 0.51 us per step, 3.58 -> 3.37 us per hand-off)
+            const bool pub_next = PACK && cr == 1 && s < its;
+            const bool pub_drop =
+                tile == 0 && A.debug_drop > 0 && (int)(epoch + 1 - A.epoch0) == A.debug_drop;
+            early_done = pub_next;
+            const __amdgpu_buffer_rsrc_t rn_next = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)A.gnew[(epoch + 1) & 1], 0, (int)A.granule_bytes, 0x00020000);
             if constexpr (PACK) {
 #pragma unroll
                 for (int sl = 0; sl < RPT; ++sl) {
@@ -627,6 +641,10 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                             out = q2 * (q1 * t);
                         }
                         Xo[r] = out;
+                        // last step of a round: the own rows leave at once, with the number of
+                        // the hand-off that follows (the rest of the step runs under their flight)
+                        if (pub_next && !pub_drop && r < n0)
+                            publish(rn_next, gr[sl], out, epoch + 1);
                     }
                 }
             } else {
