@@ -68,7 +68,7 @@ int kkt_set_option(kkt_handle h, const char *key, const char *value) {
         static const char *known[] = {"sell_r", "sell_sort", "no_graph", "persistent", "prog_mode",
                                       "prog_waves", "prog_steps", "tile_depth", "tile_waves",
                                       "lanes", "lane_chunks", "kernarg_ops", "shared_rows",
-                                      "verbose", "stamps", "tile_poll_delay",
+                                      "verbose", "stamps", "tile_poll_delay", "tile_unfused",
                                       "debug_drop_handoff"};
         if (!key || !value) fail(KKT_ERR_ARG, "null option");
         bool ok = false;

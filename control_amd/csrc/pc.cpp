@@ -394,7 +394,8 @@ bool SchurPC::fuse_tile_run(size_t k, size_t e, std::vector<PcStep> &out) {
     };
     int max_terms = 0;
     for (const TileLevel &L : levels) max_terms = std::max(max_terms, (int)L.n_upd);
-    if (tile_sweep_fuses_update(tile_plan_.W, max_terms)) {
+    if (tile_sweep_fuses_update(tile_plan_.W, max_terms) &&
+        !(tile_plan_.W > 9 && S_.opt("tile_unfused"))) {
         for (size_t q = k; q < e; ++q) (void)hipFree(steps_[q].rows.d_ops);
         tile_step(levels.data(), (int)levels.size(), (int)(e - k), true);
         return true;

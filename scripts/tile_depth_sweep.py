@@ -20,6 +20,7 @@ for waves in os.environ.get("WAVES", "0").split():
             if depth != "0": opts["tile_depth"] = depth
             if delay != "0": opts["tile_poll_delay"] = delay
             if waves != "0": opts["tile_waves"] = waves
+            if os.environ.get("UNFUSED"): opts["tile_unfused"] = "1"
             g = common.gpu_system(p, share_values=False, options=opts)
             pc = common.gpu_pc(p, p["mass"], p["schur"])
             g._set_pc(pc)

@@ -382,9 +382,11 @@ def test_minres_reports_an_indefinite_preconditioner_and_refuses_right_side():
 
 @pytest.mark.parametrize("CN", [False, True])
 def test_preconditioner_parity_3d_tile_form(CN):
-    """3-D P1 (15 entries per row): the tile form without the fused update -- one plain launch
-    for b -= U u_prev and one tile launch per time level, hand-off tags counting through the
-    launches -- against the oracle and, bit for bit, against the plain launches."""
+    """3-D P1 (15 entries per row): the tile form for wide rows -- with the level update in the
+    kernel (its matrix passing through the registers of the level matrix) where every update
+    has one term, and without (option ``tile_unfused``, and wherever an update has two terms:
+    one plain launch for b -= U u_prev and one tile launch per time level, hand-off tags counting
+    through the launches) -- against the oracle and, bit for bit, against the plain launches."""
     p = common.heat_problem(space="p1_3d", n=16, n_t=5, CN=CN)
     osys = common.oracle_system(p)
     mass, schur = (20, 0.5, 2.5), (7, 0.05, 2.1)
@@ -399,3 +401,6 @@ def test_preconditioner_parity_3d_tile_form(CN):
         x, common.gpu_pc(p, mass, schur))
     assert np.array_equal(got, plain)
     assert g.info()["program_fallbacks"] == 0
+    g2 = common.gpu_system(p, options={"prog_mode": "tile", "tile_unfused": "1"})
+    assert np.array_equal(got, g2.pc_apply(x, common.gpu_pc(p, mass, schur)))
+    assert g2.info()["program_fallbacks"] == 0
