@@ -235,11 +235,18 @@ void comm_exchange_row_halos(System &S, const double *d_y) {
     if (!S.comm) fail(KKT_ERR_STATE, "time-sharded system without a transport");
     const int up = S.rank + 1 < S.world ? S.rank + 1 : -1;
     const int dn = S.rank > 0 ? S.rank - 1 : -1;
-    // T_1 on variable 0 needs rho0 of block hi: my first rho0 block -> rank-1
-    S.comm->sendrecv(d_y + S.local_offset(0, 0), S.nx0, dn, S.d_halo_r0_hi, S.nx0, up, S.stream);
-    // T_2 on variable 1 needs rho1 of block lo-1: my last rho1 block -> rank+1
-    S.comm->sendrecv(d_y + S.local_offset(1, S.n1_loc - 1), S.nx1, up, S.d_halo_r1_lo, S.nx1, dn,
-                     S.stream);
+    // one exchange per group of blocks with its own transform (a variable, or one family of a
+    // variable): T_1 reads the first block of the rank above, T_2 the last block of the rank below
+    for (const TimeGroup &g : S.time_groups) {
+        const double *yb = d_y + (g.first_local_block < S.n0_loc
+                                      ? (int64_t)g.first_local_block * S.nx0
+                                      : (int64_t)S.n0_loc * S.nx0 +
+                                            (int64_t)(g.first_local_block - S.n0_loc) * S.nx1);
+        if (g.kind == 1)
+            S.comm->sendrecv(yb, g.nx, dn, g.d_halo, g.nx, up, S.stream);
+        else
+            S.comm->sendrecv(yb + (int64_t)(g.n - 1) * g.nx, g.nx, up, g.d_halo, g.nx, dn, S.stream);
+    }
 }
 
 }  // namespace kkt

@@ -250,6 +250,7 @@ class StokesPC : public PcBase {
     } B_, Kp_, Mp_;
     double *in_ = nullptr, *out_ = nullptr, *h_ = nullptr, *m_ = nullptr, *g_ = nullptr;
     double *P_[3] = {nullptr, nullptr, nullptr};
+    double *halo_a_ = nullptr, *halo_b_ = nullptr;   // CN on time shards: neighbour blocks of the T scans
     std::vector<void *> owned_;
     std::vector<RowLaunch> lin_, kp_steps_, mp_steps_;
     DevMat upload(int64_t nrows, int64_t ncols, const int32_t *ip, const int32_t *ix,

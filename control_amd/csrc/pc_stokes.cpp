@@ -129,7 +129,6 @@ StokesPC::StokesPC(System &outer, System &inner, System &commutator, const kkt_p
     if (outer.sharded != inner.sharded || outer.sharded != commutator.sharded)
         fail(KKT_ERR_STATE, "outer, velocity and commutator systems must be sharded alike");
     if (outer.sharded) {
-        if (cn_) fail(KKT_ERR_STATE, "time-sharded StokesPC: Crank-Nicolson branch not supported");
         if (outer.families != 2 || inner.families != 1 || commutator.families != 1 ||
             outer.lo != inner.lo || outer.hi != inner.hi || outer.lo != commutator.lo ||
             outer.hi != commutator.hi)
@@ -166,6 +165,10 @@ StokesPC::StokesPC(System &outer, System &inner, System &commutator, const kkt_p
     m_ = vec(n1);
     g_ = vec(n1);
     for (int k = 0; k < 3; ++k) P_[k] = vec(n1);
+    if (cn_ && outer.sharded) {
+        halo_a_ = vec(np_);
+        halo_b_ = vec(np_);
+    }
     // h_k = s2 (sB B u0_k - b1_k), k over the 2n blocks (v blocks then zeta blocks pair with
     // the mu blocks then p blocks: control.py:1030-1041, 4571-4601)
     {
@@ -231,12 +234,29 @@ void StokesPC::run() {
         launch_rowops(st, L.d_ops, L.nops, L.max_slices, L.R, B, 1, L.uniform_w);
     if (cn_) {   // control.py:4407-4428
         const int64_t half = (int64_t)n_ * np_;
-        launch_time_transform(st, h_, h_, 2, n_, np_, nullptr, nullptr);
-        launch_time_transform(st, h_ + half, h_ + half, 1, n_, np_, nullptr, nullptr);
+        // Time shards: T_2 / T_1 read the neighbour ranks' old blocks (one exchange each way);
+        // the inverse transforms are scans through all levels -- a rank waits for the scanned
+        // block of the rank before it, scans its levels and passes its own last one on.
+        const bool sh = S_.sharded;
+        const int up = sh && S_.rank + 1 < S_.world ? S_.rank + 1 : -1;
+        const int dn = sh && S_.rank > 0 ? S_.rank - 1 : -1;
+        double *last_a = h_ + (int64_t)(n_ - 1) * np_, *first_b = h_ + half;
+        if (sh) {
+            S_.comm->sendrecv(last_a, np_, up, halo_a_, np_, dn, st);
+            S_.comm->sendrecv(first_b, np_, dn, halo_b_, np_, up, st);
+        }
+        launch_time_transform(st, h_, h_, 2, n_, np_, dn >= 0 ? halo_a_ : nullptr, nullptr);
+        launch_time_transform(st, h_ + half, h_ + half, 1, n_, np_, nullptr,
+                              up >= 0 ? halo_b_ : nullptr);
         launch_axpby(st, h_, -1.0, in_ + n0, 1.0, 2 * half);
         launch_axpby(st, h_, 0.0, in_ + n0, s2_, 2 * half);
-        launch_time_transform(st, h_, h_, 4, n_, np_, nullptr, nullptr);
-        launch_time_transform(st, h_ + half, h_ + half, 3, n_, np_, nullptr, nullptr);
+        if (dn >= 0) S_.comm->sendrecv(nullptr, 0, -1, halo_a_, np_, dn, st);
+        launch_time_transform(st, h_, h_, 4, n_, np_, dn >= 0 ? halo_a_ : nullptr, nullptr);
+        if (up >= 0) S_.comm->sendrecv(last_a, np_, up, nullptr, 0, -1, st);
+        if (up >= 0) S_.comm->sendrecv(nullptr, 0, -1, halo_b_, np_, up, st);
+        launch_time_transform(st, h_ + half, h_ + half, 3, n_, np_, nullptr,
+                              up >= 0 ? halo_b_ : nullptr);
+        if (dn >= 0) S_.comm->sendrecv(first_b, np_, dn, nullptr, 0, -1, st);
     }
     for (const RowLaunch &L : kp_steps_)
         launch_rowops(st, L.d_ops, L.nops, L.max_slices, L.R, B, 1, L.uniform_w);

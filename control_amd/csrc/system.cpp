@@ -67,8 +67,7 @@ System::~System() {
     F(d_const_jobs);
     F(d_halo_x0_lo);
     F(d_halo_x1_hi);
-    F(d_halo_r0_hi);
-    F(d_halo_r1_lo);
+    for (TimeGroup &g : time_groups) F(g.d_halo);
     for (auto &a : d_halo2)
         for (auto &b : a)
             for (double *q : b) F(q);
@@ -119,10 +118,13 @@ void System::set_shard(int rank_, int world_, int families_) {
     if (families_ != 1 && families_ != 2) fail(KKT_ERR_ARG, "1 or 2 block families");
     if (world_ == 1) return;
     if (n0 != n1) fail(KKT_ERR_ARG, "time sharding needs n_blocks_00 == n_blocks_11");
-    if (sub00 >= 0) fail(KKT_ERR_ARG, "time sharding with sub-block splits is not supported");
-    if (families_ == 2 && CN)
-        fail(KKT_ERR_ARG, "time sharding of a two-family Crank-Nicolson system is not supported");
     if (n0 % families_ != 0) fail(KKT_ERR_ARG, "block count is not a multiple of the families");
+    // a sub-block split (the incompressible outer system: other time transforms on the second
+    // half of each variable's blocks, preconditioner.py:471-525) shards when the split is the
+    // family boundary
+    if (sub00 >= 0 && !(families_ == 2 && sub00 == n0 / 2 && sub11 == n1 / 2))
+        fail(KKT_ERR_ARG, "time sharding with sub-block splits needs two families split at the "
+                          "sub-block boundary");
     families = families_;
     mf = n0 / families;
     if (world_ > mf) fail(KKT_ERR_ARG, "more ranks than time levels");
@@ -680,7 +682,15 @@ void System::finalize() {
 
     // ---- CN time transforms (preconditioner.py:437-525)
     if (CN) {
-        if (sub00 < 0) {
+        if (sharded && families == 2) {
+            // local blocks of a variable: family 0 levels [lo, hi), then family 1 levels [lo, hi)
+            const int nl = hi - lo;
+            const bool split = sub00 >= 0;     // without a split both families of a variable
+            time_groups.push_back(TimeGroup{0, nl, 1, nx0});              // share its transform
+            time_groups.push_back(TimeGroup{nl, nl, split ? 2 : 1, nx0});
+            time_groups.push_back(TimeGroup{n0_loc, nl, 2, nx1});
+            time_groups.push_back(TimeGroup{n0_loc + nl, nl, split ? 1 : 2, nx1});
+        } else if (sub00 < 0) {
             time_groups.push_back(TimeGroup{0, n0_loc, 1, nx0});
             time_groups.push_back(TimeGroup{n0_loc, n1_loc, 2, nx1});
         } else {
@@ -733,9 +743,9 @@ void System::finalize() {
         d_halo_x1_hi = dev_alloc<double>(nx1);
         HIPCHK(hipMemset(d_halo_x0_lo, 0, nx0 * 8));
         HIPCHK(hipMemset(d_halo_x1_hi, 0, nx1 * 8));
-        if (CN) {
-            d_halo_r0_hi = dev_alloc<double>(nx0);
-            d_halo_r1_lo = dev_alloc<double>(nx1);
+        for (TimeGroup &g : time_groups) {
+            g.d_halo = dev_alloc<double>(g.nx);
+            HIPCHK(hipMemset(g.d_halo, 0, g.nx * 8));
         }
     }
     HIPCHK(hipStreamSynchronize(stream));
@@ -862,8 +872,8 @@ void System::apply(const double *d_x, double *d_y) {
                                           (int64_t)(g.first_local_block - n0_loc) * nx1);
             const double *lo_h = nullptr, *hi_h = nullptr;
             if (sharded) {
-                if (g.kind == 1 && hi < n0) hi_h = d_halo_r0_hi;
-                if (g.kind == 2 && lo > 0) lo_h = d_halo_r1_lo;
+                if (g.kind == 1 && hi < mf) hi_h = g.d_halo;
+                if (g.kind == 2 && lo > 0) lo_h = g.d_halo;
             }
             launch_time_transform(stream, yb, yb, g.kind, g.n, g.nx, lo_h, hi_h);
         }

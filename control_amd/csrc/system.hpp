@@ -109,6 +109,8 @@ struct TimeGroup {   // CN transform applied to a contiguous range of local bloc
     int n;
     int kind;                // 1: T_1, 2: T_2
     int64_t nx;
+    double *d_halo = nullptr;   // time-sharded: the neighbour rank's block the transform reads
+                                // (T_1: level hi from the rank above, T_2: level lo - 1 from below)
 };
 
 class PcBase;
@@ -189,7 +191,6 @@ struct System {
     int64_t const_max_nx = 0;
     // halos (time-sharded): x0 block lo-1, x1 block hi; CN raw rows rho0_hi, rho1_{lo-1}
     double *d_halo_x0_lo = nullptr, *d_halo_x1_hi = nullptr;
-    double *d_halo_r0_hi = nullptr, *d_halo_r1_lo = nullptr;
 
     // byte accounting
     kkt_info info{};

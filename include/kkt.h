@@ -106,7 +106,9 @@ int kkt_set_shard(kkt_handle h, int rank, int world);
 /* The same for systems whose flat blocks are `families` runs of time levels per variable
  * (2: the outer incompressible system -- velocity blocks (v, zeta), pressure blocks (mu, p),
  * control.py:3654-3673): the rank owns levels [lo, hi) of every family, local vectors are
- * [family 0 levels lo..hi-1, family 1 levels lo..hi-1] per variable.  Backward Euler only. */
+ * [family 0 levels lo..hi-1, family 1 levels lo..hi-1] per variable.  With Crank-Nicolson the
+ * sub-block split of the time transforms (sub_n_blocks_*_0, preconditioner.py:471-525) must be
+ * the family boundary. */
 int kkt_set_shard_families(kkt_handle h, int rank, int world, int families);
 /* Row range owned by `rank` of `world` for `m` block rows (pure host arithmetic). */
 int kkt_shard_range(int m, int rank, int world, int *lo, int *hi);

@@ -57,12 +57,21 @@ def run_rank(rank, world, conns, CN, ksp, out_q):
 
 
 def run_rank_stokes(rank, world, conns, out_q):
-    """Time-sharded instationary Stokes control (BE): the outer system is sharded by levels of
-    its two block families, the nested velocity solve and the commutator product by theirs."""
+    _stokes_rank(rank, world, conns, out_q, False)
+
+
+def run_rank_stokes_cn(rank, world, conns, out_q):
+    _stokes_rank(rank, world, conns, out_q, True)
+
+
+def _stokes_rank(rank, world, conns, out_q, CN):
+    """Time-sharded instationary Stokes control: the outer system is sharded by levels of its two
+    block families (Crank-Nicolson: the sub-block split of the time transforms is the family
+    boundary), the nested velocity solve and the commutator product by theirs."""
     try:
         import common
         from control_amd.dist import CallbackComm, PipeTransport, shard_range
-        p = common.stokes_problem(n=4, n_t=6, CN=False)
+        p = common.stokes_problem(n=4, n_t=7 if CN else 6, CN=CN)
         th, m = p["th"], p["m"]
         lo, hi = shard_range(m, rank, world)
         nl = hi - lo

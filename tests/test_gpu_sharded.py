@@ -65,12 +65,15 @@ def test_sharded_matches_oracle(world, CN):
         assert res[r]["hist"] == res[0]["hist"]
 
 
+@pytest.mark.parametrize("CN", [False, True])
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_stokes_matches_oracle(world):
+def test_sharded_stokes_matches_oracle(world, CN):
     """Time-sharded StokesPC (SURVEY 8f-1 on several GPUs; BASELINE configs[2] and [4] name the
-    multi-GPU split): operator, one preconditioner application and a manufactured solve of every
-    rank's shard against the single-rank oracle."""
-    res = launch(world, False, "fgmres", target="run_rank_stokes")
+    multi-GPU split), backward Euler and Crank-Nicolson (time transforms with halo blocks on the
+    four block families of the outer operator, pipelined scans in the preconditioner): operator,
+    one preconditioner application and a manufactured solve of every rank's shard against the
+    single-rank oracle."""
+    res = launch(world, CN, "fgmres", target="run_rank_stokes_cn" if CN else "run_rank_stokes")
     for r in range(world):
         d = res[r]
         assert d["e_op"] < 1e-13, d
