@@ -146,12 +146,22 @@ class GpuLinearSolver:
     values of the blocks that carry the re-linearised operator."""
 
     def __init__(self, pb: NavierStokesControl, *, mass, schur, kp, mp, solver_parameters,
-                 device=0):
+                 device=0, comm=None, host_allreduce=None):
+        """``comm`` (``control_amd.dist``): the three systems are time-sharded (BASELINE
+        configs[4] names 8 GPUs) -- every rank runs the same Picard loop on the whole iterate
+        (residual and re-linearisation are host work on replicated data, as cheap as in the
+        reference), uploads the blocks of its own levels, solves for its shard of the update,
+        and the shards are summed into the whole update with ``host_allreduce(array, op)``
+        (in place over ranks, op 0 = sum: e.g. ``GlooTransport.allreduce``)."""
         self.pb, self.device = pb, device
         self.specs = dict(mass=mass, schur=schur, kp=kp, mp=mp)
         self.solver_parameters = solver_parameters
         self.outer = None
         self.uploads = 0
+        self.dist = comm if comm is not None and comm.world > 1 else None
+        self.host_allreduce = host_allreduce
+        if self.dist is not None and host_allreduce is None:
+            raise ValueError("a time-sharded GpuLinearSolver needs host_allreduce")
 
     def _blocks(self, D, Dp):
         th, pb = self.pb.disc, self.pb
@@ -168,12 +178,13 @@ class GpuLinearSolver:
             th.n_v, th.n_p, *bl["outer"], n_blocks_00=2 * m, n_blocks_11=2 * m,
             nullspace_0=(nsv,) * (2 * m),
             nullspace_1=tuple(ConstantNullspace() for _ in range(2 * m)), device=self.device,
-            CN=pb.CN, **kw)
+            CN=pb.CN, comm=self.dist, shard_families=2, **kw)
         self.inner = MultiBlockSystem(th.n_v, th.n_v, *bl["inner"], n_blocks_00=m,
                                       n_blocks_11=m, nullspace_0=(nsv,) * m,
-                                      nullspace_1=(nsv,) * m, device=self.device, CN=pb.CN)
+                                      nullspace_1=(nsv,) * m, device=self.device, CN=pb.CN,
+                                      comm=self.dist)
         self.comm = MultiBlockSystem(th.n_p, th.n_p, *bl["commutator"], n_blocks_00=m,
-                                     n_blocks_11=m, device=self.device)
+                                     n_blocks_11=m, device=self.device, comm=self.dist)
         s = self.specs
         inner_pc = SchurPC(kind="CN" if pb.CN else "BE", M=th.M_v, beta=pb.beta, bc_nodes=th.boundary_v,
                            mass=ChebSpec(*s["mass"]), schur=ChebSpec(*s["schur"]), n_t=pb.n_t,
@@ -190,21 +201,26 @@ class GpuLinearSolver:
         m = bl["m"]
         i00, i01, i10, i11 = bl["inner"]
         c00, c01, c10, c11 = bl["commutator"]
+        own = self._owns
         for (i, j), A in i01.items():          # -> outer block_00 (i, m + j)
-            if A is not None:
+            if A is not None and own(i):
                 self.inner.update_block_values(1, i, j, A)
                 self.outer.update_block_values(0, i, m + j, A)
                 self.uploads += 2
         for (i, j), A in i10.items():          # -> outer block_00 (m + i, j)
-            if A is not None:
+            if A is not None and own(i):
                 self.inner.update_block_values(2, i, j, A)
                 self.outer.update_block_values(0, m + i, j, A)
                 self.uploads += 2
         for q, blk in ((1, c01), (2, c10)):
             for (i, j), A in blk.items():
-                if A is not None:
+                if A is not None and own(i):
                     self.comm.update_block_values(q, i, j, A)
                     self.uploads += 1
+
+    def _owns(self, level):
+        """Block rows of time level ``level`` live on this rank."""
+        return self.dist is None or self.inner._lo <= level < self.inner._hi
 
     def linear_solve(self, D, Dp, b_0, b_1):
         bl = self._blocks(D, Dp)
@@ -214,8 +230,21 @@ class GpuLinearSolver:
             self._update(bl)
         u_0 = np.zeros_like(b_0)
         u_1 = np.zeros_like(b_1)
-        ksp = self.outer.solve(u_0, u_1, b_0, b_1, solver_parameters=self.solver_parameters,
-                               pc_fn=self.pc)
+        if self.dist is None:
+            ksp = self.outer.solve(u_0, u_1, b_0, b_1, solver_parameters=self.solver_parameters,
+                                   pc_fn=self.pc)
+            return u_0, u_1, ksp.getIterationNumber()
+        # this rank's levels of both block families of a variable: rows [lo, hi) and m + [lo, hi)
+        m, lo, hi = bl["m"], self.inner._lo, self.inner._hi
+        pick = list(range(lo, hi)) + list(range(m + lo, m + hi))
+        l_0, l_1 = np.zeros_like(b_0[pick]), np.zeros_like(b_1[pick])
+        ksp = self.outer.solve(l_0, l_1, np.ascontiguousarray(b_0[pick]),
+                               np.ascontiguousarray(b_1[pick]),
+                               solver_parameters=self.solver_parameters, pc_fn=self.pc)
+        u_0[pick], u_1[pick] = l_0, l_1
+        for u in (u_0, u_1):            # the other ranks' rows are zero here: a sum gathers
+            flat = u.reshape(-1)
+            self.host_allreduce(flat, 0)
         return u_0, u_1, ksp.getIterationNumber()
 
 

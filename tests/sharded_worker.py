@@ -106,3 +106,45 @@ def _stokes_rank(rank, world, conns, out_q, CN):
     except Exception as e:
         import traceback
         out_q.put((rank, "error", traceback.format_exc() + repr(e)))
+
+
+def run_rank_picard(rank, world, conns, out_q):
+    _picard_rank(rank, world, conns, out_q, False)
+
+
+def run_rank_picard_cn(rank, world, conns, out_q):
+    _picard_rank(rank, world, conns, out_q, True)
+
+
+def _picard_rank(rank, world, conns, out_q, CN):
+    """Time-sharded Picard loop of Navier-Stokes control (BASELINE configs[4] names 8 GPUs):
+    lid-driven cavity of test/test_control.py:4171-4268 at 4 x 4, n_t = 6 (5 blocks with CN),
+    nu = 0.2; every rank keeps the whole iterate, solves for its levels, the update is summed
+    over the ranks on the host.  Compared with the same loop on one rank."""
+    try:
+        import common
+        from control_amd import picard
+        from control_amd.dist import CallbackComm, PipeTransport
+        pb, v_init, _ = common.navier_stokes_cavity_problem(n=4, n_t=7 if CN else 6, CN=CN)
+        pb.nu = 0.2
+        s = common.STOKES_SPECS
+        kw = dict(mass=s["mass"], schur=s["schur"], kp=s["kp"], mp=s["mp"],
+                  solver_parameters=common.NS_SOLVER_PARAMETERS)
+        ref = picard.incompressible_non_linear_solve(pb, picard.GpuLinearSolver(pb, **kw),
+                                                     v=v_init, print_error_non_linear=False)
+        tr = PipeTransport(rank, world, conns)
+        comm = CallbackComm(rank, world, tr.allreduce, tr.sendrecv)
+        gls = picard.GpuLinearSolver(pb, comm=comm, host_allreduce=tr.allreduce, **kw)
+        out = picard.incompressible_non_linear_solve(pb, gls, v=v_init,
+                                                     print_error_non_linear=False)
+        out_q.put((rank, "ok", dict(
+            converged=out["converged"], n=len(out["norms"]), n_ref=len(ref["norms"]),
+            e_norms=float(max(abs(a - b) / ref["norms"][0]
+                              for a, b in zip(out["norms"], ref["norms"]))),
+            e_v=float(np.abs(out["v"] - ref["v"]).max()),
+            e_p=float(np.abs(out["p"] - ref["p"]).max()),
+            its=out["linear_iterations"], its_ref=ref["linear_iterations"],
+            uploads=gls.uploads, hist=[float(x) for x in out["norms"]])))
+    except Exception as e:
+        import traceback
+        out_q.put((rank, "error", traceback.format_exc() + repr(e)))

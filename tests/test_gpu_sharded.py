@@ -83,6 +83,19 @@ def test_sharded_stokes_matches_oracle(world, CN):
         assert res[r]["hist"] == res[0]["hist"]
 
 
+@pytest.mark.parametrize("CN", [False, True])
+def test_sharded_picard_loop_matches_one_rank(CN):
+    """Navier-Stokes control (BASELINE configs[4]: Picard loop on 8 GPUs) with the
+    linearised solves time-sharded over two ranks: same number of Picard iterations, residual
+    history and fields as the loop on one rank, identical on both ranks."""
+    res = launch(2, CN, "fgmres", target="run_rank_picard_cn" if CN else "run_rank_picard")
+    for r in range(2):
+        d = res[r]
+        assert d["converged"] and d["n"] == d["n_ref"], d
+        assert d["e_norms"] < 1e-6 and d["e_v"] < 1e-6 and d["e_p"] < 1e-5, d
+    assert res[0]["hist"] == res[1]["hist"]
+
+
 def test_rccl_transport_single_rank():
     """RCCL is loaded, a communicator is created and the collectives used by bench.py
     (barrier = all-reduce of one double, max) run -- world size 1, the only RCCL shape a
