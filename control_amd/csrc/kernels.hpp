@@ -134,6 +134,7 @@ struct TileArgs {
     int32_t fused_update;                     // 0: kernel variant without the level update
 };
 bool tile_sweep_available(int W, int rpt, int threads);
+int tile_sweep_max_rpt(int W, int threads);   // most row slots per thread of any variant (0: none)
 // whether the variant for this shape computes the level update b -= U u_prev itself (narrow
 // rows); wide rows (3-D P1) have no registers for it: the update stays a launch of its own
 bool tile_sweep_fuses_update(int W, int max_terms);   // update terms of any level of the run

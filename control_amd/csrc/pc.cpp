@@ -300,13 +300,21 @@ bool SchurPC::prepare_tiles() {
     const uint8_t *hm = hmask.empty() ? nullptr : hmask.data();
     if (tw) {
         threads = 64 * std::max(1, std::min(16, std::atoi(tw)));
-        if (!build_tile_plan(P, ntiles, depth, threads, threads > 512 ? 1 : 3, tile_plan_, hm, schur_its_))
+        // (the depth model must only consider what a kernel variant exists for: wide rows have
+        // one or two row slots, and a deeper plan that needs more would lose the tile form)
+        if (!build_tile_plan(P, ntiles, depth, threads,
+                             std::max(1, tile_sweep_max_rpt(P.max_width, threads)), tile_plan_, hm,
+                             schur_its_))
             return false;
     } else {
         TilePlan big;
-        const bool ok_big = build_tile_plan(P, ntiles, depth, 1024, 1, big, hm, schur_its_) &&
+        const bool ok_big = tile_sweep_max_rpt(P.max_width, 1024) >= 1 &&
+                            build_tile_plan(P, ntiles, depth, 1024, 1, big, hm, schur_its_) &&
                             tile_sweep_available(big.W, big.rpt, 1024);
-        const bool ok_small = build_tile_plan(P, ntiles, depth, 512, 3, tile_plan_, hm, schur_its_) &&
+        const bool ok_small = tile_sweep_max_rpt(P.max_width, 512) >= 1 &&
+                              build_tile_plan(P, ntiles, depth, 512,
+                                              tile_sweep_max_rpt(P.max_width, 512), tile_plan_, hm,
+                                              schur_its_) &&
                               tile_sweep_available(tile_plan_.W, tile_plan_.rpt, 512);
         if (!ok_big && !ok_small) return false;
         if (ok_big && (!ok_small || big.model_us <= tile_plan_.model_us)) tile_plan_ = big;

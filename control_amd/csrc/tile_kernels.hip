@@ -789,6 +789,13 @@ size_t tile_sweep_lds_bytes(int nk_pad, int its) {
     return (2 * (size_t)nk_pad + 3 * (size_t)std::max(1, its - 1) + 1) * sizeof(double);
 }
 
+int tile_sweep_max_rpt(int W, int threads) {
+    int best = 0;
+    for (int rpt = 1; rpt <= 4; ++rpt)
+        if (pick_tile(W, rpt, threads)) best = rpt;
+    return best;
+}
+
 bool tile_sweep_available(int W, int rpt, int threads) {
     return threads >= 64 && threads <= 1024 && threads % 64 == 0 &&
            pick_tile(W, rpt, threads) != nullptr;

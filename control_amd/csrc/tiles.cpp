@@ -57,6 +57,26 @@ struct Bisector {
         ++cur;
         for (int32_t v : nodes) stamp[v] = cur;
         const int32_t a = bfs(nodes, nodes[0]);
+        // A disconnected subset (vector-valued blocks whose components do not couple are copies
+        // of one graph side by side): the component of the first row gets its share of the
+        // parts, the rest theirs.  Ordered along one axis, the unreached rows would all sit at
+        // "distance difference 0" and end up in tiles made of pieces of both components
+        // (P2 velocity block 128^2: 777 ring rows around 509 own rows).
+        if (queue.size() < nodes.size()) {
+            std::vector<int32_t> reached(queue.begin(), queue.end()), rest;
+            rest.reserve(nodes.size() - reached.size());
+            const int32_t big = dist[a] + 1;
+            for (int32_t v : nodes)
+                if (dist[v] == big) rest.push_back(v);
+            std::sort(reached.begin(), reached.end());
+            int nr = (int)(((int64_t)nparts * (int64_t)reached.size() + (int64_t)nodes.size() / 2) /
+                           (int64_t)nodes.size());
+            nr = std::max(1, std::min(nparts - 1, nr));
+            std::vector<int32_t>().swap(nodes);
+            run(reached, nr, base);
+            run(rest, nparts - nr, base + nr);
+            return;
+        }
         const int32_t b = bfs(nodes, a);
         std::vector<int32_t> da(nodes.size());
         for (size_t i = 0; i < nodes.size(); ++i) da[i] = dist[nodes[i]];

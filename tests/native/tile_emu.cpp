@@ -3,6 +3,7 @@
 // and the previous iterate), tiles advanced in lock step.  Compared bit for bit with the plain
 // global recurrence.  Test infrastructure: checks the plan and the scheme, not the GPU kernel.
 //   usage: tile_emu <nx> <ny> <ntiles> <depth (0 = auto)> <threads> <its> <nlevels>
+//                   [mask-aware tiles 0/1] [components: interleaved uncoupled copies of the grid]
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -22,21 +23,25 @@ int main(int argc, char **argv) {
     const int ntiles = argc > 3 ? std::atoi(argv[3]) : 12, depth_in = argc > 4 ? std::atoi(argv[4]) : 0;
     const int T = argc > 5 ? std::atoi(argv[5]) : 64, its = argc > 6 ? std::atoi(argv[6]) : 11;
     const int nlev = argc > 7 ? std::atoi(argv[7]) : 3;
-    // P1-like 7-point structure on an nx x ny grid (right-diagonal triangulation)
+    // P1-like 7-point structure on an nx x ny grid (right-diagonal triangulation); with
+    // `ncomp` > 1: that many uncoupled copies, interleaved node by node (a vector-valued block)
+    const int ncomp = argc > 9 ? std::atoi(argv[9]) : 1;
     Pattern P;
-    const int n = nx * ny;
+    const int n = nx * ny * ncomp;
     P.nrows = P.ncols = n;
     P.R = 2;
     P.h_indptr.push_back(0);
     const int dx[7] = {-1, 0, -1, 0, 1, 0, 1}, dy[7] = {-1, -1, 0, 0, 0, 1, 1};
     for (int j = 0; j < ny; ++j)
-        for (int i = 0; i < nx; ++i) {
-            for (int q = 0; q < 7; ++q) {
-                const int ii = i + dx[q], jj = j + dy[q];
-                if (ii >= 0 && ii < nx && jj >= 0 && jj < ny) P.h_indices.push_back(jj * nx + ii);
+        for (int i = 0; i < nx; ++i)
+            for (int c = 0; c < ncomp; ++c) {
+                for (int q = 0; q < 7; ++q) {
+                    const int ii = i + dx[q], jj = j + dy[q];
+                    if (ii >= 0 && ii < nx && jj >= 0 && jj < ny)
+                        P.h_indices.push_back((jj * nx + ii) * ncomp + c);
+                }
+                P.h_indptr.push_back((int32_t)P.h_indices.size());
             }
-            P.h_indptr.push_back((int32_t)P.h_indices.size());
-        }
     P.nnz = P.h_indices.size();
     P.max_width = 7;
     P.uniform_w = 7;
@@ -47,7 +52,8 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> mask(n, 0);
     for (int j = 0; j < ny; ++j)
         for (int i = 0; i < nx; ++i)
-            if (i == 0 || j == 0 || i == nx - 1 || j == ny - 1) mask[j * nx + i] = 1;
+            if (i == 0 || j == 0 || i == nx - 1 || j == ny - 1)
+                for (int c = 0; c < ncomp; ++c) mask[(j * nx + i) * ncomp + c] = 1;
     const bool mask_aware = argc > 8 ? std::atoi(argv[8]) != 0 : true;
     TilePlan tp;
     if (!build_tile_plan(P, ntiles, depth_in, T, 4, tp, mask_aware ? mask.data() : nullptr)) {

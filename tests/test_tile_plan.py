@@ -30,6 +30,18 @@ CASES = [(33, 29, 12, 0, 64, 11, 3),       # ragged tile sizes, modelled depth
          (257, 257, 256, 0, 512, 20, 2)]   # BASELINE configs[1] mesh, one tile per CU
 
 
+def test_uncoupled_components_get_tiles_of_their_own(emu):
+    """A vector-valued block whose components do not couple (P2 velocity blocks: two copies of
+    the scalar graph, interleaved node by node) is partitioned component by component: tiles made
+    of pieces of both copies had 256 ring rows around 127 own rows on this mesh, 67 now."""
+    r = subprocess.run([emu, "129", "129", "256", "1", "512", "6", "2", "1", "2"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "mismatches: 0 of" in r.stdout
+    halo = int(r.stdout.split("halo")[1].split()[0])
+    assert halo <= 80, r.stdout
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_tile_scheme_is_bit_identical_to_plain_recurrence(emu, case):
     r = subprocess.run([emu] + [str(c) for c in case], capture_output=True, text=True)
