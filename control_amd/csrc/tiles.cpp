@@ -62,16 +62,23 @@ struct Bisector {
         // parts, the rest theirs.  Ordered along one axis, the unreached rows would all sit at
         // "distance difference 0" and end up in tiles made of pieces of both components
         // (P2 velocity block 128^2: 777 ring rows around 509 own rows).
-        if (queue.size() < nodes.size()) {
+        // (only where both sides deserve a part of their own: a half of a connected mesh often
+        // has slivers cut off from it, and those stay with the ordering below)
+        const int nr = (int)(((int64_t)nparts * (int64_t)queue.size() + (int64_t)nodes.size() / 2) /
+                             (int64_t)nodes.size());
+        auto balanced = [&]() {      // no part more than 5 % above the average size
+            const double avg = (double)nodes.size() / nparts;
+            const double sr = (double)queue.size() / nr;
+            const double su = (double)(nodes.size() - queue.size()) / (nparts - nr);
+            return sr <= 1.05 * avg && su <= 1.05 * avg;
+        };
+        if (queue.size() < nodes.size() && nr >= 1 && nr <= nparts - 1 && balanced()) {
             std::vector<int32_t> reached(queue.begin(), queue.end()), rest;
             rest.reserve(nodes.size() - reached.size());
             const int32_t big = dist[a] + 1;
             for (int32_t v : nodes)
                 if (dist[v] == big) rest.push_back(v);
             std::sort(reached.begin(), reached.end());
-            int nr = (int)(((int64_t)nparts * (int64_t)reached.size() + (int64_t)nodes.size() / 2) /
-                           (int64_t)nodes.size());
-            nr = std::max(1, std::min(nparts - 1, nr));
             std::vector<int32_t>().swap(nodes);
             run(reached, nr, base);
             run(rest, nparts - nr, base + nr);

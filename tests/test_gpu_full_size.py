@@ -27,6 +27,24 @@ def _log(msg, t0):
     print(f"[full-size] {msg}: {time.time() - t0:.1f} s", flush=True)
 
 
+def _sweep_launches(gsys, gpc, x):
+    """(persistent sweep launches, dependent SpMV steps in them) of one preconditioner
+    application -- ``kkt_time_pc_sweeps``, the entry point behind bench.py's ``roofline_sweeps``.
+    0 launches: the time sweeps run as plain launches (no persistent form fitted)."""
+    import ctypes as C
+    from control_amd import _lib
+    gsys._set_pc(gpc)
+    lib, h = gsys._lib, gsys.handle
+    d_x, d_y = C.c_void_p(), C.c_void_p()
+    gsys._ck(lib.kkt_vec_alloc(h, C.byref(d_x)))
+    gsys._ck(lib.kkt_vec_alloc(h, C.byref(d_y)))
+    gsys._ck(lib.kkt_vec_upload(h, d_x, _lib.f64(x)[1]))
+    ms, launches, phases = C.c_float(), C.c_int(), C.c_int64()
+    gsys._ck(lib.kkt_time_pc_sweeps(h, d_x, d_y, C.byref(ms), C.byref(launches),
+                                    C.byref(phases)))
+    return launches.value, phases.value
+
+
 # ------------------------------------------------------------------ configs[1]
 CFG2_MASS, CFG2_SCHUR = (20, 0.5, 2.0), (80, 7.0e-4, 2.1)      # bench.py defaults
 
@@ -67,6 +85,9 @@ def test_config2_bench_preconditioner_against_oracle_and_plain_launches(cfg2):
     ref = osys.pc_apply(common.oracle_pc(p, CFG2_MASS, CFG2_SCHUR), x)
     _log("+ numpy oracle", t0)
     assert common.rel_err(got, ref) < 1e-9
+    # the form the bench line is about: one persistent launch per time sweep, every one of the
+    # 2 x 64 x 80 dependent steps inside them
+    assert _sweep_launches(g, common.gpu_pc(p, CFG2_MASS, CFG2_SCHUR), x) == (2, 2 * 64 * 80)
     c = cref.CRef(p["blocks"], p["m"], p["sd"].n_dofs, p["nodes"], p["sd"].M, p["n_t"],
                   p["tau"], p["beta"], CFG2_MASS, CFG2_SCHUR)
     xc = x.reshape(2 * p["m"], -1).copy()
@@ -191,6 +212,9 @@ def test_config4_heat3d_full_size():
     gc = got.reshape(2 * p["m"], -1)
     ref[:, p["nodes"]] = gc[:, p["nodes"]]
     assert common.rel_err(gc, ref) < 1e-9
+    # (a tile plan that stops fitting would silently put 64^3 back on plain launches, 2.7x slower)
+    launches, phases = _sweep_launches(g, common.gpu_pc(p, CFG4_MASS, CFG4_SCHUR), x)
+    assert launches == 2 and phases >= 2 * 127 * 34, (launches, phases)
     g.set_option("persistent", "0")
     plain = g.pc_apply(x, common.gpu_pc(p, CFG4_MASS, CFG4_SCHUR))
     _log("+ plain launches", t0)
