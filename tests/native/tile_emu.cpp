@@ -4,6 +4,8 @@
 // global recurrence.  Test infrastructure: checks the plan and the scheme, not the GPU kernel.
 //   usage: tile_emu <nx> <ny> <ntiles> <depth (0 = auto)> <threads> <its> <nlevels>
 //                   [mask-aware tiles 0/1] [components: interleaved uncoupled copies of the grid]
+//                   [nz: > 1 = 3-D grid nx x ny x nz with the 15-point structure of Kuhn cubes]
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -26,34 +28,54 @@ int main(int argc, char **argv) {
     // P1-like 7-point structure on an nx x ny grid (right-diagonal triangulation); with
     // `ncomp` > 1: that many uncoupled copies, interleaved node by node (a vector-valued block)
     const int ncomp = argc > 9 ? std::atoi(argv[9]) : 1;
+    const int nz = argc > 10 ? std::max(1, std::atoi(argv[10])) : 1;
     Pattern P;
-    const int n = nx * ny * ncomp;
+    const int n = nx * ny * nz * ncomp;
     P.nrows = P.ncols = n;
     P.R = 2;
     P.h_indptr.push_back(0);
     const int dx[7] = {-1, 0, -1, 0, 1, 0, 1}, dy[7] = {-1, -1, 0, 0, 0, 1, 1};
-    for (int j = 0; j < ny; ++j)
-        for (int i = 0; i < nx; ++i)
-            for (int c = 0; c < ncomp; ++c) {
-                for (int q = 0; q < 7; ++q) {
-                    const int ii = i + dx[q], jj = j + dy[q];
-                    if (ii >= 0 && ii < nx && jj >= 0 && jj < ny)
-                        P.h_indices.push_back((jj * nx + ii) * ncomp + c);
+    // Kuhn cubes: the three axes, the three face diagonals and the space diagonal, both ways
+    const int ex[7] = {1, 0, 0, 1, 0, 1, 1}, ey[7] = {0, 1, 0, 1, 1, 0, 1}, ez[7] = {0, 0, 1, 0, 1, 1, 1};
+    const int WS = nz > 1 ? 15 : 7;
+    for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i)
+                for (int c = 0; c < ncomp; ++c) {
+                    if (nz == 1) {
+                        for (int q = 0; q < 7; ++q) {
+                            const int ii = i + dx[q], jj = j + dy[q];
+                            if (ii >= 0 && ii < nx && jj >= 0 && jj < ny)
+                                P.h_indices.push_back((jj * nx + ii) * ncomp + c);
+                        }
+                    } else {
+                        std::vector<int32_t> row;
+                        row.push_back(((k * ny + j) * nx + i) * ncomp + c);
+                        for (int q = 0; q < 7; ++q)
+                            for (int sg = -1; sg <= 1; sg += 2) {
+                                const int ii = i + sg * ex[q], jj = j + sg * ey[q], kk = k + sg * ez[q];
+                                if (ii >= 0 && ii < nx && jj >= 0 && jj < ny && kk >= 0 && kk < nz)
+                                    row.push_back(((kk * ny + jj) * nx + ii) * ncomp + c);
+                            }
+                        std::sort(row.begin(), row.end());
+                        P.h_indices.insert(P.h_indices.end(), row.begin(), row.end());
+                    }
+                    P.h_indptr.push_back((int32_t)P.h_indices.size());
                 }
-                P.h_indptr.push_back((int32_t)P.h_indices.size());
-            }
     P.nnz = P.h_indices.size();
-    P.max_width = 7;
-    P.uniform_w = 7;
+    P.max_width = WS;
+    P.uniform_w = WS;
     P.nslices = (n + 127) / 128;
-    for (int s = 0; s <= P.nslices; ++s) P.h_slice_off.push_back(7 * s);
-    P.npadded = (int64_t)7 * P.nslices * 128;
+    for (int s = 0; s <= P.nslices; ++s) P.h_slice_off.push_back(WS * s);
+    P.npadded = (int64_t)WS * P.nslices * 128;
     // boundary rows: masked (their iterates are zero); argv[8] = 0 keeps them inside the tiles
     std::vector<uint8_t> mask(n, 0);
-    for (int j = 0; j < ny; ++j)
-        for (int i = 0; i < nx; ++i)
-            if (i == 0 || j == 0 || i == nx - 1 || j == ny - 1)
-                for (int c = 0; c < ncomp; ++c) mask[(j * nx + i) * ncomp + c] = 1;
+    for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i)
+                if (i == 0 || j == 0 || i == nx - 1 || j == ny - 1 ||
+                    (nz > 1 && (k == 0 || k == nz - 1)))
+                    for (int c = 0; c < ncomp; ++c) mask[((k * ny + j) * nx + i) * ncomp + c] = 1;
     const bool mask_aware = argc > 8 ? std::atoi(argv[8]) != 0 : true;
     TilePlan tp;
     if (!build_tile_plan(P, ntiles, depth_in, T, 4, tp, mask_aware ? mask.data() : nullptr)) {

@@ -42,6 +42,15 @@ def test_uncoupled_components_get_tiles_of_their_own(emu):
     assert halo <= 80, r.stdout
 
 
+def test_wide_rows_of_a_3d_mesh(emu):
+    """15-point structure of Kuhn cubes (3-D P1), Dirichlet faces outside the tiles, depth 2 with
+    three row slots: the scheme on rows wider than the 2-D ones and rings that outgrow the tiles."""
+    r = subprocess.run([emu, "17", "17", "24", "2", "128", "7", "3", "1", "1", "13"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "mismatches: 0 of" in r.stdout
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_tile_scheme_is_bit_identical_to_plain_recurrence(emu, case):
     r = subprocess.run([emu] + [str(c) for c in case], capture_output=True, text=True)
