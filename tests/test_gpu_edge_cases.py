@@ -266,14 +266,14 @@ def test_sweep_program_timeout_falls_back_to_plain_launches():
     x = common.rng_vector(2 * p["m"] * p["sd"].n_dofs)
     ref = common.gpu_system(p, options={"persistent": "0"}).pc_apply(
         x, common.gpu_pc(p, (20, 0.5, 2.0), schur))
-    g = common.gpu_system(p, options={"prog_mode": "tile", "debug_drop_handoff": "3"})
+    g = common.gpu_system(p, options={"persistent": "1", "prog_mode": "tile", "debug_drop_handoff": "3"})
     got = g.pc_apply(x, common.gpu_pc(p, (20, 0.5, 2.0), schur))
     assert np.array_equal(got, ref)
     assert g.info()["program_fallbacks"] == 1
     msg = g._lib.kkt_last_error(g.handle).decode()
     assert "tile form" in msg and "plain launches" in msg
     # and inside a solve: it starts over from the caller's guess
-    g2 = common.gpu_system(p, options={"prog_mode": "tile", "debug_drop_handoff": "3"})
+    g2 = common.gpu_system(p, options={"persistent": "1", "prog_mode": "tile", "debug_drop_handoff": "3"})
     m, nx = p["m"], p["sd"].n_dofs
     b = x.reshape(2 * m, nx)
     sp_ = {"linear_solver": "gmres", "gmres_restart": 10, "maximum_iterations": 8,

@@ -297,7 +297,7 @@ def test_timed_sweep_programs_give_the_preconditioner_result(CN):
     import ctypes as C
     from control_amd import _lib
     p = common.heat_problem(n=24, n_t=6, CN=CN)
-    gsys = common.gpu_system(p)
+    gsys = common.gpu_system(p, options={"persistent": "1"})    # whatever KKT_PERSISTENT says
     gpc = common.gpu_pc(p, MASS, (12, 0.05, 2.2))
     x = common.rng_vector(2 * p["m"] * p["sd"].n_dofs)
     ref = gsys.pc_apply(x, gpc)
