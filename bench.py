@@ -278,6 +278,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config4", action="store_true",
                     help="skip the side leg on BASELINE configs[3] (3-D heat 64^3, n_t = 128)")
+    ap.add_argument("--no-tile-coordinates", action="store_true",
+                    help="do not pass the dof coordinates as the tiling hint of the sweep programs")
     ap.add_argument("--only-spmv", action="store_true",
                     help="time the KKT SpMV only (counter-collection passes)")
     args = ap.parse_args()
@@ -339,7 +341,8 @@ def measure_heat(args, rank, world, local_rank, tts):
     # with KKT_TRANSPORT=gloo); production: one GPU per local rank
     device = int(os.environ.get("KKT_DEVICE", local_rank))
     t_setup = time.perf_counter()
-    gsys = common.gpu_system(p, device=device, comm=comm, share_values=p["share_values"])
+    gsys = common.gpu_system(p, device=device, comm=comm, share_values=p["share_values"],
+                             tile_coordinates=not args.no_tile_coordinates)
     lib, h = gsys._lib, gsys.handle
     gpc = common.gpu_pc(p, p["mass"], p["schur"])
     gsys._set_pc(gpc)

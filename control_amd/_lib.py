@@ -72,6 +72,7 @@ SIGNATURES = {
     "kkt_destroy": (C.c_int, [C.c_void_p]),
     "kkt_last_error": (C.c_char_p, [C.c_void_p]),
     "kkt_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
+    "kkt_set_tile_coordinates": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_f64p]),
     "kkt_set_layout": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                  C.c_int, C.c_int, C.c_int]),
     "kkt_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

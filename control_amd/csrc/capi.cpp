@@ -78,6 +78,14 @@ int kkt_set_option(kkt_handle h, const char *key, const char *value) {
     });
 }
 
+int kkt_set_tile_coordinates(kkt_handle h, int dim, int64_t n, const double *coords) {
+    KKT_TRY(h, {
+        if (dim < 1 || dim > 3 || n < 1 || !coords) fail(KKT_ERR_ARG, "bad tile coordinates");
+        S.tile_coords.assign(coords, coords + (size_t)n * dim);
+        S.tile_dim = dim;
+    });
+}
+
 int kkt_set_layout(kkt_handle h, int n00, int n11, int64_t nx0, int64_t nx1, int CN, int s00,
                    int s11) {
     KKT_TRY(h, S.set_layout(n00, n11, nx0, nx1, CN, s00, s11));

@@ -298,23 +298,26 @@ bool SchurPC::prepare_tiles() {
         for (int32_t k : bc_idx_) hmask[k] = 1;
     }
     const uint8_t *hm = hmask.empty() ? nullptr : hmask.data();
+    // coordinates of the rows, if the caller gave them (kkt_set_tile_coordinates)
+    const double *tc = (S_.tile_dim > 0 && (int64_t)S_.tile_coords.size() == P.nrows * S_.tile_dim)
+                           ? S_.tile_coords.data() : nullptr;
     if (tw) {
         threads = 64 * std::max(1, std::min(16, std::atoi(tw)));
         // (the depth model must only consider what a kernel variant exists for: wide rows have
         // one or two row slots, and a deeper plan that needs more would lose the tile form)
         if (!build_tile_plan(P, ntiles, depth, threads,
                              std::max(1, tile_sweep_max_rpt(P.max_width, threads)), tile_plan_, hm,
-                             schur_its_))
+                             schur_its_, tc, S_.tile_dim))
             return false;
     } else {
         TilePlan big;
         const bool ok_big = tile_sweep_max_rpt(P.max_width, 1024) >= 1 &&
-                            build_tile_plan(P, ntiles, depth, 1024, 1, big, hm, schur_its_) &&
+                            build_tile_plan(P, ntiles, depth, 1024, 1, big, hm, schur_its_, tc, S_.tile_dim) &&
                             tile_sweep_available(big.W, big.rpt, 1024);
         const bool ok_small = tile_sweep_max_rpt(P.max_width, 512) >= 1 &&
                               build_tile_plan(P, ntiles, depth, 512,
                                               tile_sweep_max_rpt(P.max_width, 512), tile_plan_, hm,
-                                              schur_its_) &&
+                                              schur_its_, tc, S_.tile_dim) &&
                               tile_sweep_available(tile_plan_.W, tile_plan_.rpt, 512);
         if (!ok_big && !ok_small) return false;
         if (ok_big && (!ok_small || big.model_us <= tile_plan_.model_us)) tile_plan_ = big;

@@ -209,6 +209,8 @@ struct System {
     // execution options (kkt_set_option); a key that was never set falls back to the
     // environment variable KKT_<KEY> (developer scripts), then to the built-in default
     std::map<std::string, std::string> options;
+    std::vector<double> tile_coords;   // kkt_set_tile_coordinates: N_x x tile_dim, or empty
+    int tile_dim = 0;
     const char *opt(const char *key) const;
     // Krylov workspace (lazily sized)
     int ws_restart = 0;

@@ -130,7 +130,7 @@ void TilePlan::release() {
 }
 
 bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int max_rpt,
-                     TilePlan &out, const uint8_t *mask, int its) {
+                     TilePlan &out, const uint8_t *mask, int its, const double *coords, int dim) {
     if (P.nrows != P.ncols || ntiles < 1 || depth > TILE_MAX_DEPTH) return false;
     const bool auto_depth = depth <= 0;
     if (auto_depth) depth = TILE_MAX_DEPTH;
@@ -144,14 +144,59 @@ bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int m
     if (out.W < 1) return false;
     out.part.assign(nrows, -1);
     {
-        Bisector B(P, out.part);
         std::vector<int32_t> all;
         all.reserve(nrows);
         for (int64_t r = 0; r < nrows; ++r)
             if (!mask || !mask[r]) all.push_back((int32_t)r);
         if ((int64_t)ntiles > (int64_t)all.size()) ntiles = (int)std::max<size_t>(1, all.size());
         out.ntiles = ntiles;
-        B.run(all, ntiles, 0);
+        if (coords != nullptr && dim >= 1) {
+            // recursive coordinate bisection: cut the longest extent at the proportional
+            // position (ties by the other coordinates, then by row: deterministic)
+            struct Rcb {
+                const double *c;
+                int dim;
+                std::vector<int32_t> &part;
+                void run(std::vector<int32_t> &nodes, int nparts, int base) {
+                    if (nparts <= 1 || nodes.size() <= 1) {
+                        for (int32_t v : nodes) part[v] = base;
+                        return;
+                    }
+                    int ax = 0;
+                    double best = -1.0;
+                    for (int a = 0; a < dim; ++a) {
+                        double lo = 1e300, hi = -1e300;
+                        for (int32_t v : nodes) {
+                            lo = std::min(lo, c[(size_t)v * dim + a]);
+                            hi = std::max(hi, c[(size_t)v * dim + a]);
+                        }
+                        if (hi - lo > best) {
+                            best = hi - lo;
+                            ax = a;
+                        }
+                    }
+                    std::sort(nodes.begin(), nodes.end(), [&](int32_t x, int32_t y) {
+                        for (int q = 0; q < dim; ++q) {
+                            const int a = (ax + q) % dim;
+                            const double cx = c[(size_t)x * dim + a], cy = c[(size_t)y * dim + a];
+                            if (cx != cy) return cx < cy;
+                        }
+                        return x < y;
+                    });
+                    const int nl = nparts / 2;
+                    const size_t cut = (size_t)(((int64_t)nodes.size() * nl + nparts / 2) / nparts);
+                    std::vector<int32_t> left(nodes.begin(), nodes.begin() + cut),
+                        right(nodes.begin() + cut, nodes.end());
+                    std::vector<int32_t>().swap(nodes);
+                    run(left, nl, base);
+                    run(right, nparts - nl, base + nl);
+                }
+            } rcb{coords, dim, out.part};
+            rcb.run(all, ntiles, 0);
+        } else {
+            Bisector B(P, out.part);
+            B.run(all, ntiles, 0);
+        }
     }
     // rings: L_0 = own rows, L_{j+1} = L_j + columns of the rows of L_j
     std::vector<std::vector<int32_t>> local(ntiles);   // global rows in local order

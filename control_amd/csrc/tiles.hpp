@@ -53,7 +53,10 @@ struct TilePlan {
 // and whose columns are zeroed in every matrix of a sweep -- belong to no tile and to no ring;
 // columns that point at them read the tile's permanent zero slot (local index nk_pad - 1).
 // `its` (0: unknown): dependent steps per level, for the depth model (hand-offs counted whole).
+// `coords` (may be null; nrows x dim): the rows' coordinates -- the parts are then boxes from
+// recursive coordinate bisection (largest extent first) instead of graph bisection.
 bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int max_rpt,
-                     TilePlan &out, const uint8_t *mask = nullptr, int its = 0);
+                     TilePlan &out, const uint8_t *mask = nullptr, int its = 0,
+                     const double *coords = nullptr, int dim = 0);
 
 }  // namespace kkt

@@ -302,6 +302,18 @@ class MultiBlockSystem:
         self._ck(self._lib.kkt_set_option(self._h, str(key).encode(), str(value).encode()))
         self._pc_state = None if key != "verbose" else getattr(self, "_pc_state", None)
 
+    def set_tile_coordinates(self, coords):
+        """``kkt_set_tile_coordinates``: coordinates of the dofs of a spatial block of variable 0,
+        shape ``(N_x, dim)`` -- an optional hint for the tiling of the preconditioner's sweep
+        programs (boxes instead of graph bisection; results do not depend on it).  Before the
+        preconditioner is first used."""
+        c = np.ascontiguousarray(np.asarray(coords, dtype=np.float64))
+        if c.ndim != 2 or c.shape[0] != self._nx0 or not 1 <= c.shape[1] <= 3:
+            raise ValueError("tile coordinates must have shape (N_x of space_0, 1..3)")
+        self._ck(self._lib.kkt_set_tile_coordinates(self._h, c.shape[1], c.shape[0],
+                                                    c.ctypes.data_as(_lib.c_f64p)))
+        self._pc_state = None
+
     def info(self):
         inf = _lib.Info()
         self._ck(self._lib.kkt_get_info(self._h, C.byref(inf)))

@@ -183,6 +183,8 @@ class GpuLinearSolver:
                                       n_blocks_11=m, nullspace_0=(nsv,) * m,
                                       nullspace_1=(nsv,) * m, device=self.device, CN=pb.CN,
                                       comm=self.dist)
+        if getattr(th, "coords_v", None) is not None and 2 * len(th.coords_v) == th.n_v:
+            self.inner.set_tile_coordinates(np.vstack([th.coords_v, th.coords_v]))
         self.comm = MultiBlockSystem(th.n_p, th.n_p, *bl["commutator"], n_blocks_00=m,
                                      n_blocks_11=m, device=self.device, comm=self.dist)
         s = self.specs

@@ -28,12 +28,17 @@ def heat_problem(space="p1", n=10, n_t=10, beta=1.0e-4, T=2.0, CN=False, share=T
                 blocks=(b00, b01, b10, b11), nodes=sd.boundary)
 
 
-def gpu_system(p, **kw):
+def gpu_system(p, tile_coordinates=True, **kw):
+    """``tile_coordinates``: hand the dof coordinates to the library as the tiling hint of the
+    sweep programs (``kkt_set_tile_coordinates``; speed only)."""
     from .multiblock import DirichletBCNullspace, MultiBlockSystem
     sd, m = p["sd"], p["m"]
     ns = tuple(DirichletBCNullspace(p["nodes"]) for _ in range(m))
-    return MultiBlockSystem(sd.n_dofs, sd.n_dofs, *p["blocks"], n_blocks_00=m,
-                            n_blocks_11=m, nullspace_0=ns, nullspace_1=ns, CN=p["CN"], **kw)
+    g = MultiBlockSystem(sd.n_dofs, sd.n_dofs, *p["blocks"], n_blocks_00=m,
+                         n_blocks_11=m, nullspace_0=ns, nullspace_1=ns, CN=p["CN"], **kw)
+    if tile_coordinates and getattr(sd, "coords", None) is not None:
+        g.set_tile_coordinates(sd.coords)
+    return g
 
 
 def gpu_pc(p, mass, schur):
@@ -76,6 +81,8 @@ def stokes_gpu(p, specs=STOKES_SPECS, options=None, comm=None):
     inner = MultiBlockSystem(th.n_v, th.n_v, *bl["inner"], n_blocks_00=m, n_blocks_11=m,
                              nullspace_0=(nsv,) * m, nullspace_1=(nsv,) * m, CN=CN,
                              options=options, comm=comm)
+    if getattr(th, "coords_v", None) is not None and 2 * len(th.coords_v) == th.n_v:
+        inner.set_tile_coordinates(np.vstack([th.coords_v, th.coords_v]))   # component-major
     # the commutator product is a plain block product (control.py:4625-4665): no transforms
     # (time-sharded with `comm`: the outer system by levels of its two block families, the
     # velocity and commutator systems by their levels -- the same [lo, hi) on a rank)

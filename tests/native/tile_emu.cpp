@@ -5,6 +5,7 @@
 //   usage: tile_emu <nx> <ny> <ntiles> <depth (0 = auto)> <threads> <its> <nlevels>
 //                   [mask-aware tiles 0/1] [components: interleaved uncoupled copies of the grid]
 //                   [nz: > 1 = 3-D grid nx x ny x nz with the 15-point structure of Kuhn cubes]
+//                   [coordinates 0/1: tiles by coordinate bisection instead of graph bisection]
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -77,8 +78,20 @@ int main(int argc, char **argv) {
                     (nz > 1 && (k == 0 || k == nz - 1)))
                     for (int c = 0; c < ncomp; ++c) mask[((k * ny + j) * nx + i) * ncomp + c] = 1;
     const bool mask_aware = argc > 8 ? std::atoi(argv[8]) != 0 : true;
+    const bool use_coords = argc > 11 && std::atoi(argv[11]) != 0;
+    std::vector<double> xyz;
+    if (use_coords)
+        for (int k = 0; k < nz; ++k)
+            for (int j = 0; j < ny; ++j)
+                for (int i = 0; i < nx; ++i)
+                    for (int c = 0; c < ncomp; ++c) {
+                        xyz.push_back(i);
+                        xyz.push_back(j);
+                        xyz.push_back(k);
+                    }
     TilePlan tp;
-    if (!build_tile_plan(P, ntiles, depth_in, T, 4, tp, mask_aware ? mask.data() : nullptr)) {
+    if (!build_tile_plan(P, ntiles, depth_in, T, 4, tp, mask_aware ? mask.data() : nullptr, 0,
+                         use_coords ? xyz.data() : nullptr, 3)) {
         std::printf("plan does not fit\n");
         return 3;
     }

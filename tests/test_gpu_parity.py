@@ -74,6 +74,11 @@ def test_preconditioner_parity_many_workgroups(CN):
         other = common.gpu_system(p, options={var: val}).pc_apply(
             x, common.gpu_pc(p, MASS, schur))
         assert np.array_equal(got, other), (var, val)
+    # the tiles: boxes from the dof coordinates (the default of gpu_system) or parts from the
+    # bisection of the sparsity graph -- the partition changes nothing in the result
+    other = common.gpu_system(p, tile_coordinates=False, options={"prog_mode": "tile"}).pc_apply(
+        x, common.gpu_pc(p, MASS, schur))
+    assert np.array_equal(got, other)
 
 
 KRYLOV_SCHUR = (12, 0.08, 2.1)   # beta = 1e-2 on the 10x10 mesh: kappa(D^-1 S) ~ 25
@@ -404,3 +409,6 @@ def test_preconditioner_parity_3d_tile_form(CN):
     g2 = common.gpu_system(p, options={"prog_mode": "tile", "tile_unfused": "1"})
     assert np.array_equal(got, g2.pc_apply(x, common.gpu_pc(p, mass, schur)))
     assert g2.info()["program_fallbacks"] == 0
+    g3 = common.gpu_system(p, tile_coordinates=False, options={"prog_mode": "tile"})
+    assert np.array_equal(got, g3.pc_apply(x, common.gpu_pc(p, mass, schur)))   # graph bisection
+    assert g3.info()["program_fallbacks"] == 0

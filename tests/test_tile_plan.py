@@ -51,6 +51,20 @@ def test_wide_rows_of_a_3d_mesh(emu):
     assert "mismatches: 0 of" in r.stdout
 
 
+def test_tiles_from_coordinates(emu):
+    """With the rows' coordinates the parts are boxes (recursive coordinate bisection): same
+    scheme, smaller rings than the graph bisection's slanted parts -- 257^2 at depth 7: 630
+    against 784 ring rows; 65^3 at depth 1: 760 against 1 030 (33^3 in 64 tiles: 448 against 512); two uncoupled components share
+    their nodes' coordinates and tiles."""
+    for args, bound in ((["257", "257", "256", "7", "1024", "4", "2", "1", "1", "1", "1"], 640),
+                        (["33", "33", "64", "1", "512", "4", "2", "1", "1", "33", "1"], 460),
+                        (["129", "129", "256", "1", "512", "6", "2", "1", "2", "1", "1"], 80)):
+        r = subprocess.run([emu] + args, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "mismatches: 0 of" in r.stdout
+        assert int(r.stdout.split("halo")[1].split()[0]) <= bound, r.stdout
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_tile_scheme_is_bit_identical_to_plain_recurrence(emu, case):
     r = subprocess.run([emu] + [str(c) for c in case], capture_output=True, text=True)
