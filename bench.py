@@ -481,6 +481,8 @@ def measure_heat(args, rank, world, local_rank, tts):
                                f"Schur Chebyshev {p['schur']} (its, emin, emax)"),
             "parallelism": f"time-block rows over {world} GPU(s)",
             "transport": (getattr(comm, "name", "rccl") if world > 1 else "none"),
+            "sweep_tiles": ("boxes from the dof coordinates (kkt_set_tile_coordinates)"
+                            if not args.no_tile_coordinates else "bisection of the sparsity graph"),
             "pc_apply_ms": pc_ms, "kkt_apply_ms": spmv_ms, "setup_s": t_setup,
             "time_to_solution": t_sol},
         "roofline": {
