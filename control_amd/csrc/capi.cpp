@@ -1,4 +1,5 @@
 // extern "C" boundary of libkkt (include/kkt.h).  No C++ exception leaves this file.
+#include <cmath>
 #include <cstring>
 #include <string>
 
@@ -81,6 +82,8 @@ int kkt_set_option(kkt_handle h, const char *key, const char *value) {
 int kkt_set_tile_coordinates(kkt_handle h, int dim, int64_t n, const double *coords) {
     KKT_TRY(h, {
         if (dim < 1 || dim > 3 || n < 1 || !coords) fail(KKT_ERR_ARG, "bad tile coordinates");
+        for (size_t i = 0; i < (size_t)n * dim; ++i)      // (they are sorted: no NaN)
+            if (!std::isfinite(coords[i])) fail(KKT_ERR_ARG, "tile coordinates must be finite");
         S.tile_coords.assign(coords, coords + (size_t)n * dim);
         S.tile_dim = dim;
     });

@@ -371,3 +371,23 @@ def test_sharded_handle_rejects_blocks_whose_halo_is_not_exchanged():
         assert add(1, 2, 1) == -1                          # Q01 reading x1 of level lo - 1
     finally:
         lib.kkt_destroy(h)
+
+
+def test_tile_coordinates_are_a_checked_hint():
+    """``kkt_set_tile_coordinates``: wrong shapes and non-finite values are refused; coordinates
+    that are useless for tiling (all rows at one point) still give the plain launches' result."""
+    p = common.heat_problem(n=24, n_t=4)
+    nx = p["sd"].n_dofs
+    g = common.gpu_system(p, tile_coordinates=False, options={"prog_mode": "tile"})
+    with pytest.raises(ValueError):
+        g.set_tile_coordinates(np.zeros((nx + 1, 2)))
+    bad = np.array(p["sd"].coords, dtype=np.float64)
+    bad[3, 0] = np.nan
+    with pytest.raises(Exception, match="finite"):
+        g.set_tile_coordinates(bad)
+    g.set_tile_coordinates(np.zeros((nx, 2)))              # degenerate: ties broken by row index
+    x = common.rng_vector(2 * p["m"] * nx)
+    pc = (20, 0.5, 2.0), (9, 0.05, 2.1)
+    got = g.pc_apply(x, common.gpu_pc(p, *pc))
+    plain = common.gpu_system(p, options={"persistent": "0"}).pc_apply(x, common.gpu_pc(p, *pc))
+    assert np.array_equal(got, plain)
