@@ -192,7 +192,36 @@ bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int m
                     run(right, nparts - nl, base + nl);
                 }
             } rcb{coords, dim, out.part};
-            rcb.run(all, ntiles, 0);
+            // Rows that share their coordinates are the components of a vector-valued space: every
+            // component gets tiles of its own (a tile of both has the rings of both).  Component
+            // = rank of a row among the rows at its point.
+            std::vector<int32_t> order(all);
+            std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+                for (int a = 0; a < dim; ++a) {
+                    const double cx = coords[(size_t)x * dim + a], cy = coords[(size_t)y * dim + a];
+                    if (cx != cy) return cx < cy;
+                }
+                return x < y;
+            });
+            auto same_point = [&](int32_t x, int32_t y) {
+                for (int a = 0; a < dim; ++a)
+                    if (coords[(size_t)x * dim + a] != coords[(size_t)y * dim + a]) return false;
+                return true;
+            };
+            std::vector<std::vector<int32_t>> comp;
+            for (size_t i = 0, k = 0; i < order.size(); ++i) {
+                k = (i > 0 && same_point(order[i - 1], order[i])) ? k + 1 : 0;
+                if (comp.size() <= k) comp.resize(k + 1);
+                comp[k].push_back(order[i]);
+            }
+            bool even = comp.size() > 1 && (int)comp.size() <= ntiles && ntiles % (int)comp.size() == 0;
+            for (const auto &c : comp) even = even && c.size() == comp[0].size();
+            if (even) {
+                const int per = ntiles / (int)comp.size();
+                for (size_t k = 0; k < comp.size(); ++k) rcb.run(comp[k], per, (int)k * per);
+            } else {
+                rcb.run(all, ntiles, 0);
+            }
         } else {
             Bisector B(P, out.part);
             B.run(all, ntiles, 0);
