@@ -132,15 +132,17 @@ struct TileArgs {
     int32_t clear;                            // zero the granule buffers before the launch (the
                                               // first tile launch of a replayed sequence)
     int32_t fused_update;                     // 0: kernel variant without the level update
+    int32_t hslots;                           // ring-entry slots per thread the plan needs
 };
-bool tile_sweep_available(int W, int rpt, int threads);
+bool tile_sweep_available(int W, int rpt, int threads, int hslots);   // hslots: ring-entry slots per thread
+int tile_sweep_max_hslots(int W, int rpt, int threads);
 int tile_sweep_max_rpt(int W, int threads);   // most row slots per thread of any variant (0: none)
 // whether the variant for this shape computes the level update b -= U u_prev itself (narrow
 // rows); wide rows (3-D P1) have no registers for it: the update stays a launch of its own
 bool tile_sweep_fuses_update(int W, int max_terms);   // update terms of any level of the run
 size_t tile_sweep_lds_bytes(int nk_pad, int its);
 // workgroups of `threads` that are certainly co-resident (one per CU)
-int tile_sweep_max_tiles(int W, int rpt, int threads, size_t lds_bytes);
+int tile_sweep_max_tiles(int W, int rpt, int threads, size_t lds_bytes, int hslots);
 void launch_tile_sweep(hipStream_t s, const TileArgs &a, const TileLevel *d_levels,
                        const int32_t *d_n, const int32_t *d_grow, const uint16_t *d_lcol,
                        const int32_t *d_gpos, const uint8_t *d_rowmask, int ntiles, int threads,

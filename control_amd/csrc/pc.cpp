@@ -307,26 +307,27 @@ bool SchurPC::prepare_tiles() {
         // one or two row slots, and a deeper plan that needs more would lose the tile form)
         if (!build_tile_plan(P, ntiles, depth, threads,
                              std::max(1, tile_sweep_max_rpt(P.max_width, threads)), tile_plan_, hm,
-                             schur_its_, tc, S_.tile_dim))
+                             schur_its_, tc, S_.tile_dim, tile_sweep_max_hslots))
             return false;
     } else {
         TilePlan big;
         const bool ok_big = tile_sweep_max_rpt(P.max_width, 1024) >= 1 &&
-                            build_tile_plan(P, ntiles, depth, 1024, 1, big, hm, schur_its_, tc, S_.tile_dim) &&
-                            tile_sweep_available(big.W, big.rpt, 1024);
+                            build_tile_plan(P, ntiles, depth, 1024, 1, big, hm, schur_its_, tc, S_.tile_dim,
+                                            tile_sweep_max_hslots) &&
+                            tile_sweep_available(big.W, big.rpt, 1024, big.hslots);
         const bool ok_small = tile_sweep_max_rpt(P.max_width, 512) >= 1 &&
                               build_tile_plan(P, ntiles, depth, 512,
                                               tile_sweep_max_rpt(P.max_width, 512), tile_plan_, hm,
-                                              schur_its_, tc, S_.tile_dim) &&
-                              tile_sweep_available(tile_plan_.W, tile_plan_.rpt, 512);
+                                              schur_its_, tc, S_.tile_dim, tile_sweep_max_hslots) &&
+                              tile_sweep_available(tile_plan_.W, tile_plan_.rpt, 512, tile_plan_.hslots);
         if (!ok_big && !ok_small) return false;
         if (ok_big && (!ok_small || big.model_us <= tile_plan_.model_us)) tile_plan_ = big;
         threads = tile_plan_.threads;
     }
     TilePlan &tp = tile_plan_;
-    if (!tp.symmetric || !tile_sweep_available(tp.W, tp.rpt, threads)) return false;
+    if (!tp.symmetric || !tile_sweep_available(tp.W, tp.rpt, threads, tp.hslots)) return false;
     const size_t lds = tile_sweep_lds_bytes(tp.nk_pad, std::max(schur_its_, 2));
-    if (tp.ntiles > tile_sweep_max_tiles(tp.W, tp.rpt, threads, lds)) return false;
+    if (tp.ntiles > tile_sweep_max_tiles(tp.W, tp.rpt, threads, lds, tp.hslots)) return false;
     tp.upload();
     const size_t words = 2 * (size_t)P.nrows;
     for (int i = 0; i < 4; ++i) {
@@ -1300,6 +1301,7 @@ void SchurPC::replay(size_t first, size_t last) {
                 a.epoch0 = s.epoch0;
                 a.clear = s.clear ? 1 : 0;
                 a.fused_update = s.fused ? 1 : 0;
+                a.hslots = tp.hslots;
                 a.stamps = S_.opt("stamps") != nullptr;
                 {
                     const char *dd = S_.opt("debug_drop_handoff");

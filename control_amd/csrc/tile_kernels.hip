@@ -71,12 +71,21 @@ __device__ __forceinline__ LevEarly read_early(const TileLevel *p) {
     return f;
 }
 
-template <int W, int RPT, int TMAX, bool UPD>
+// (an opaque read of a packed column register: the decode -- shift / mask, times 8 plus the vector's
+// base -- then stays inside the step loop instead of being hoisted into registers of its own:
+// 18 of the 28 registers the two-slot P2 variant is short of)
+__device__ __forceinline__ unsigned opaque(unsigned x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// HPT_: ring-entry slots per thread of a hand-off (RPT + 1 unless the variant is short of registers)
+template <int W, int RPT, int TMAX, bool UPD, int HPT_ = RPT + 1>
 __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     const TileArgs A, const TileLevel *__restrict__ levels, const int32_t *__restrict__ n_all,
     const int32_t *__restrict__ grow_all, const uint16_t *__restrict__ lcol_all,
     const int32_t *__restrict__ gpos_all, const uint8_t *__restrict__ rowmask_) {
-    constexpr int HPT = RPT + 1;
+    constexpr int HPT = HPT_;
     extern __shared__ double X[];
     __shared__ int sn[TILE_DEPTH_MAX + 1];
     __shared__ int sdead;
@@ -131,8 +140,13 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
         gr[sl] = r < nk1 ? grow[r] : -1;
         msk[sl] = gr[sl] >= 0 && rowmask != nullptr && rowmask[gr[sl]] != 0;
     }
+    // (variants short of registers read the packed columns opaquely -- see opaque(); where the
+    // decoded offsets fit into registers, hoisting them is 2 % faster: 3-D, two slots)
+    constexpr bool OPQ = PACK && W * RPT > 30;
+#define KKT_CPK(sl, j) (OPQ ? opaque(cpk[sl][j]) : cpk[sl][j])
 #define KKT_COL(sl, k)                                                                       \
-    (int)(PACK ? (((k) & 1) ? (cpk[sl][PACK ? (k) / 2 : 0] >> 16) : (cpk[sl][PACK ? (k) / 2 : 0] & 0xffffu)) \
+    (int)(PACK ? (((k) & 1) ? (KKT_CPK(sl, PACK ? (k) / 2 : 0) >> 16)                         \
+                            : (KKT_CPK(sl, PACK ? (k) / 2 : 0) & 0xffffu))                    \
                : cpk[sl][PACK ? 0 : (k)])
 #define KKT_GP(sl, k) (PACK ? gpos[(size_t)((sl) * W + (k)) * T] : gpr[sl][PACK ? 0 : (k)])
     // ... and the ring entries it gathers at a hand-off
@@ -293,19 +307,23 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
         vals_key = (const void *)ptr;
         const gcd_p vp = (gcd_p)ptr;
         if constexpr (PACK) {
-            int gp[RPT][W];
+            constexpr int G = RPT * W > 30 ? 1 : RPT;   // slots whose positions are fetched together
 #pragma unroll
-            for (int sl = 0; sl < RPT; ++sl)
+            for (int s0 = 0; s0 < RPT; s0 += G) {
+                int gp[G][W];
 #pragma unroll
-                for (int k = 0; k < W; ++k) gp[sl][k] = KKT_GP(sl, k);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int q = 0; q < G; ++q)
 #pragma unroll
-            for (int sl = 0; sl < RPT; ++sl)
+                    for (int k = 0; k < W; ++k) gp[q][k] = KKT_GP(s0 + q, k);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int k = 0; k < W; ++k)
-                    v[sl][k] = (gp[sl][k] >= 0 && (!update_matrix || gr[sl] >= 0))
-                                   ? vp[gp[sl][k]] : 0.0;
-            __builtin_amdgcn_sched_barrier(0);
+                for (int q = 0; q < G; ++q)
+#pragma unroll
+                    for (int k = 0; k < W; ++k)
+                        v[s0 + q][k] = (gp[q][k] >= 0 && (!update_matrix || gr[s0 + q] >= 0))
+                                           ? vp[gp[q][k]] : 0.0;
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else {
 #pragma unroll
             for (int sl = 0; sl < RPT; ++sl)
@@ -746,6 +764,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
 }
 
 #undef KKT_COL
+#undef KKT_CPK
 #undef KKT_GP
 
 typedef void (*tile_fn)(const TileArgs, const TileLevel *, const int32_t *, const int32_t *,
@@ -754,7 +773,8 @@ typedef void (*tile_fn)(const TileArgs, const TileLevel *, const int32_t *, cons
 // (2-D P1) run 512 threads with up to three row slots or 1 024 with one, level update fused.
 // Wide rows (3-D P1: 15 entries, 30 registers of matrix values per row slot) run 512 threads with
 // two slots in the variant without the fused update (244 registers; with it 256 + 78 spilled).
-static tile_fn pick_tile(int W, int rpt, int threads, bool fused = true) {
+static tile_fn pick_tile(int W, int rpt, int threads, bool fused = true, int hslots = 0) {
+    if (hslots <= 0) hslots = 1;
 #define KKT_T(w)                                                           \
     if (W == w) {                                                          \
         if (threads <= 512) {                                              \
@@ -778,6 +798,10 @@ static tile_fn pick_tile(int W, int rpt, int threads, bool fused = true) {
     // P2 velocity blocks (9 or 19 entries per row, row-sorted storage): one row slot
     if (W == 19 && threads <= 512 && rpt == 1)
         return fused ? pc_tile_sweep<19, 1, 512, true> : pc_tile_sweep<19, 1, 512, false>;
+    // two slots: one ring-entry slot per thread is what the registers allow (10 spilled ones
+    // remain, all in the per-level code)
+    if (W == 19 && threads <= 512 && rpt == 2 && hslots <= 1)
+        return fused ? pc_tile_sweep<19, 2, 512, true, 1> : pc_tile_sweep<19, 2, 512, false, 1>;
     return nullptr;
 }
 
@@ -792,22 +816,29 @@ size_t tile_sweep_lds_bytes(int nk_pad, int its) {
 int tile_sweep_max_rpt(int W, int threads) {
     int best = 0;
     for (int rpt = 1; rpt <= 4; ++rpt)
-        if (pick_tile(W, rpt, threads)) best = rpt;
+        if (pick_tile(W, rpt, threads, true, 1)) best = rpt;
     return best;
 }
 
-bool tile_sweep_available(int W, int rpt, int threads) {
-    return threads >= 64 && threads <= 1024 && threads % 64 == 0 &&
-           pick_tile(W, rpt, threads) != nullptr;
+int tile_sweep_max_hslots(int W, int rpt, int threads) {
+    int best = 0;
+    for (int h = 1; h <= rpt + 1; ++h)
+        if (pick_tile(W, rpt, threads, true, h)) best = h;
+    return best;
 }
 
-int tile_sweep_max_tiles(int W, int rpt, int threads, size_t lds_bytes) {
+bool tile_sweep_available(int W, int rpt, int threads, int hslots) {
+    return threads >= 64 && threads <= 1024 && threads % 64 == 0 && hslots <= rpt + 1 &&
+           pick_tile(W, rpt, threads, true, hslots) != nullptr;
+}
+
+int tile_sweep_max_tiles(int W, int rpt, int threads, size_t lds_bytes, int hslots) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     // both variants of a width (with / without the level update) must be resident
     for (int fused = 0; fused < 2; ++fused) {
-        tile_fn f = pick_tile(W, rpt, threads, fused != 0);
+        tile_fn f = pick_tile(W, rpt, threads, fused != 0, hslots);
         int per_cu = 0;
         if (!f) return 0;
         if (lds_bytes > 48 * 1024 &&
@@ -833,7 +864,7 @@ void launch_tile_sweep(hipStream_t s, const TileArgs &a, const TileLevel *d_leve
             (void)hipMemsetAsync(a.gold[i], 0, granule_words * sizeof(unsigned long long), s);
         }
     const size_t lds = tile_sweep_lds_bytes(a.nk_pad, a.its);
-    hipLaunchKernelGGL(pick_tile(a.W, a.rpt, threads, a.fused_update != 0), dim3(ntiles), dim3(threads), lds, s, a, d_levels,
+    hipLaunchKernelGGL(pick_tile(a.W, a.rpt, threads, a.fused_update != 0, a.hslots), dim3(ntiles), dim3(threads), lds, s, a, d_levels,
                        d_n, d_grow, d_lcol, d_gpos, d_rowmask);
 }
 

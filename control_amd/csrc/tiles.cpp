@@ -130,7 +130,8 @@ void TilePlan::release() {
 }
 
 bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int max_rpt,
-                     TilePlan &out, const uint8_t *mask, int its, const double *coords, int dim) {
+                     TilePlan &out, const uint8_t *mask, int its, const double *coords, int dim,
+                     int (*max_hslots)(int W, int rpt, int threads)) {
     if (P.nrows != P.ncols || ntiles < 1 || depth > TILE_MAX_DEPTH) return false;
     const bool auto_depth = depth <= 0;
     if (auto_depth) depth = TILE_MAX_DEPTH;
@@ -268,6 +269,12 @@ bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int m
     // 1 000 rows computed: 1 024-thread workgroups 1.68 + 1.32 and 0.34 + 0.12, 512-thread
     // workgroups 1.5 + 1.5 and 0.38 + 0.16.  With the steps per level known, the hand-offs of a
     // level are counted whole (ceil(its / d): 80 steps at depth 7 are 12 rounds, at depth 6: 14).
+    // the ring entries of a tile are gathered by `hslots` slots per thread; a variant with `rp`
+    // row slots has rp + 1 of them unless the kernel table says otherwise
+    auto halo_fits = [&](int rp, int64_t ring_rows) {
+        const int cap = max_hslots ? max_hslots(out.W, rp, threads) : rp + 1;
+        return (int64_t)cap * threads >= ring_rows;
+    };
     auto model = [&](int d, double *us) -> bool {
         int64_t mk = 0, mr = 0, mh = 0, mo = 0;
         for (int t = 0; t < ntiles; ++t) {
@@ -278,7 +285,7 @@ bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int m
             mo = std::max<int64_t>(mo, nt[d - 1] - nt[0]);
         }
         int rp = (int)((mr + threads - 1) / threads);
-        while ((int64_t)(rp + 1) * threads < mh) ++rp;
+        while (rp <= max_rpt && !halo_fits(rp, mh)) ++rp;
         if (mk > 65535 || rp > max_rpt) return false;
         const bool big = threads > 512;
         const double handoff = (big ? 1.68 : 1.5) + (big ? 1.32e-3 : 1.5e-3) * (double)(mh + mo);
@@ -326,11 +333,11 @@ bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int m
     out.max_halo = max_halo;
     out.mean_redundancy = red / ntiles;
     if (max_nk + 64 > 65535) return false;
-    int rpt = (int)((max_rows + threads - 1) / threads);
-    while ((int64_t)(rpt + 1) * threads < max_halo) ++rpt;
-    if (rpt < 1) rpt = 1;
+    int rpt = std::max(1, (int)((max_rows + threads - 1) / threads));
+    while (rpt <= max_rpt && !halo_fits(rpt, max_halo)) ++rpt;
     if (rpt > max_rpt) return false;
     out.rpt = rpt;
+    out.hslots = std::max(1, (int)((max_halo + threads - 1) / threads));
     out.nk_pad = (int)((max_nk + 1 + 63) & ~(int64_t)63);   // + the zero slot at nk_pad - 1
     const int W = out.W, T = threads;
     out.grow.assign((size_t)ntiles * out.nk_pad, -1);

@@ -25,6 +25,7 @@ constexpr int TILE_MAX_DEPTH = 16;
 struct TilePlan {
     int ntiles = 0, depth = 0, threads = 0, W = 0;
     int rpt = 0;          // row slots per thread: rows [0, n[depth-1]) of a tile are computed
+    int hslots = 0;       // ring-entry slots per thread a hand-off needs: ceil(max ring rows / threads)
     int nk_pad = 0;       // LDS vector length: max over tiles of n[depth], padded
     bool symmetric = false;   // tile A gathers from tile B <=> B gathers from A
     // host copies (per tile, fixed strides)
@@ -57,6 +58,9 @@ struct TilePlan {
 // recursive coordinate bisection (largest extent first) instead of graph bisection.
 bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int max_rpt,
                      TilePlan &out, const uint8_t *mask = nullptr, int its = 0,
-                     const double *coords = nullptr, int dim = 0);
+                     const double *coords = nullptr, int dim = 0,
+                     int (*max_hslots)(int W, int rpt, int threads) = nullptr);
+// `max_hslots` (may be null: rpt + 1): ring-entry slots per thread the kernel variant with `rpt`
+// row slots has; a plan whose rings need more is not made (a deeper one would lose the tile form).
 
 }  // namespace kkt
