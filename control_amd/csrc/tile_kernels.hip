@@ -73,7 +73,13 @@ __device__ __forceinline__ LevEarly read_early(const TileLevel *p) {
 
 // (an opaque read of a packed column register: the decode -- shift / mask, times 8 plus the vector's
 // base -- then stays inside the step loop instead of being hoisted into registers of its own:
-// 18 of the 28 registers the two-slot P2 variant is short of)
+// W registers per row slot)
+template <typename P>
+__device__ __forceinline__ P opaque_ptr(P p) {
+    unsigned long long u = (unsigned long long)p;
+    asm volatile("" : "+v"(u));
+    return (P)u;
+}
 __device__ __forceinline__ unsigned opaque(unsigned x) {
     asm volatile("" : "+v"(x));
     return x;
@@ -119,6 +125,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     bool msk[RPT];
     const gcu16_p lcol = (gcu16_p)lcol_all + (size_t)tile * RPT * W * T + tid;
     const gci_p gpos = (gci_p)gpos_all + (size_t)tile * RPT * W * T + tid;
+    const gci_p gpos_base = gpos;
 #pragma unroll
     for (int sl = 0; sl < RPT; ++sl) {
         const int r = sl * T + tid;
@@ -140,9 +147,9 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
         gr[sl] = r < nk1 ? grow[r] : -1;
         msk[sl] = gr[sl] >= 0 && rowmask != nullptr && rowmask[gr[sl]] != 0;
     }
-    // (variants short of registers read the packed columns opaquely -- see opaque(); where the
-    // decoded offsets fit into registers, hoisting them is 2 % faster: 3-D, two slots)
-    constexpr bool OPQ = PACK && W * RPT > 30;
+    // (the 1 024-thread variants -- 128 registers -- read the packed columns opaquely, see
+    // opaque(); where the decoded offsets fit into registers, hoisting them is 2 % faster)
+    constexpr bool OPQ = PACK && TMAX > 512;
 #define KKT_CPK(sl, j) (OPQ ? opaque(cpk[sl][j]) : cpk[sl][j])
 #define KKT_COL(sl, k)                                                                       \
     (int)(PACK ? (((k) & 1) ? (KKT_CPK(sl, PACK ? (k) / 2 : 0) >> 16)                         \
@@ -307,6 +314,10 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
         vals_key = (const void *)ptr;
         const gcd_p vp = (gcd_p)ptr;
         if constexpr (PACK) {
+            // (the addresses of the positions must not be hoisted out of the level loop: they
+            // are 2 W registers per row slot that nothing else could use -- 58 of the 245
+            // registers of the two-slot 3-D variant)
+            const gci_p gpos = opaque_ptr(gpos_base);
             constexpr int G = RPT * W > 30 ? 1 : RPT;   // slots whose positions are fetched together
 #pragma unroll
             for (int s0 = 0; s0 < RPT; s0 += G) {
@@ -791,6 +802,10 @@ static tile_fn pick_tile(int W, int rpt, int threads, bool fused = true, int hsl
 #undef KKT_T
     // Wide rows: with the level update (one term, its matrix passing through the registers of
     // the level matrix) or without (the update stays a plain launch, one tile launch per level)
+    // 3-D tiles whose rows and ring fit one slot each: 1 024 threads (16 waves hide the step's
+    // latency chain better than 8 with two slots)
+    if (W == 15 && threads > 512 && rpt == 1 && hslots <= 1)
+        return fused ? pc_tile_sweep<15, 1, 1024, true, 1> : pc_tile_sweep<15, 1, 1024, false, 1>;
     if (W == 15 && threads <= 512) {
         if (rpt == 1) return fused ? pc_tile_sweep<15, 1, 512, true> : pc_tile_sweep<15, 1, 512, false>;
         if (rpt == 2) return fused ? pc_tile_sweep<15, 2, 512, true> : pc_tile_sweep<15, 2, 512, false>;
@@ -798,10 +813,8 @@ static tile_fn pick_tile(int W, int rpt, int threads, bool fused = true, int hsl
     // P2 velocity blocks (9 or 19 entries per row, row-sorted storage): one row slot
     if (W == 19 && threads <= 512 && rpt == 1)
         return fused ? pc_tile_sweep<19, 1, 512, true> : pc_tile_sweep<19, 1, 512, false>;
-    // two slots: one ring-entry slot per thread is what the registers allow (10 spilled ones
-    // remain, all in the per-level code)
-    if (W == 19 && threads <= 512 && rpt == 2 && hslots <= 1)
-        return fused ? pc_tile_sweep<19, 2, 512, true, 1> : pc_tile_sweep<19, 2, 512, false, 1>;
+    if (W == 19 && threads <= 512 && rpt == 2)      // 215 registers
+        return fused ? pc_tile_sweep<19, 2, 512, true> : pc_tile_sweep<19, 2, 512, false>;
     return nullptr;
 }
 
