@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round 2 profiles (copied from gpurun_out/r02_prof into profiles/r02 by hand):
+# Round 2 profiles (scripts/r02_collect_profiles.py copies them from gpurun_out/r02_prof into
+# profiles/r02):
 #   bench line, rocprofv3 kernel stats of the same command (KKT_NO_GRAPH=1: rocprofv3 of ROCm 7.2
 #   segfaults inside hipGraphLaunch of the captured preconditioner graphs; same kernels, same
 #   order), PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs) for the KKT SpMV and the tile
