@@ -50,7 +50,28 @@ class Info(C.Structure):
                  "nnz_blocks", "rows_blocks", "bytes_algorithmic",
                  "bytes_device_values", "bytes_device_index", "bytes_streamed")] + \
                [("last_solve_ms", C.c_double), ("last_pc_applies", C.c_int64),
-                ("last_op_applies", C.c_int64), ("program_fallbacks", C.c_int64)]
+                ("last_op_applies", C.c_int64), ("program_fallbacks", C.c_int64)] + \
+               [(n, C.c_int64) for n in
+                ("sweep_form", "sweep_tiles", "sweep_threads", "sweep_depth", "sweep_row_slots",
+                 "sweep_its")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class StageTimes(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("operator_ms", "pc_ms", "orth_ms", "allreduce_ms",
+                                          "other_ms", "total_ms")] + \
+               [(n, C.c_int64) for n in ("iterations", "operator_applies", "pc_applies")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class PcStageTimes(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("sweeps_ms", "batched_ms", "comm_ms", "total_ms")] + \
+               [(n, C.c_int64) for n in ("sweep_launches", "sweep_phases", "batched_launches",
+                                         "comm_steps")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -114,6 +135,9 @@ SIGNATURES = {
                                     C.POINTER(C.c_float)]),
     "kkt_time_pc_sweeps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float),
                                      C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "kkt_get_stage_times": (C.c_int, [C.c_void_p, C.POINTER(StageTimes)]),
+    "kkt_time_pc_stages": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.POINTER(PcStageTimes)]),
     "kkt_debug_set_steplock": (C.c_int, [C.c_void_p, C.POINTER(StepLock)]),
     "kkt_get_info": (C.c_int, [C.c_void_p, C.POINTER(Info)]),
     "kkt_comm_unique_id": (C.c_int, [C.c_void_p]),

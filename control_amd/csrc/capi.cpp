@@ -70,7 +70,7 @@ int kkt_set_option(kkt_handle h, const char *key, const char *value) {
                                       "prog_waves", "prog_steps", "tile_depth", "tile_waves",
                                       "lanes", "lane_chunks", "kernarg_ops", "shared_rows",
                                       "verbose", "stamps", "tile_poll_delay", "tile_unfused",
-                                      "debug_drop_handoff"};
+                                      "debug_drop_handoff", "stage_timers"};
         if (!key || !value) fail(KKT_ERR_ARG, "null option");
         bool ok = false;
         for (const char *k : known) ok = ok || std::strcmp(k, key) == 0;
@@ -217,16 +217,14 @@ int kkt_pc_apply(kkt_handle h, const double *x, double *y) {
         up(S, dx.p, x);
         S.pc_apply(dx.p, dy.p);
         if (S.pc) {
-            // a sweep program that timed out is replaced by plain launches and the application
-            // redone (same arithmetic)
+            // a sweep program that timed out (on any rank of a time shard: the decision is
+            // collective) is replaced by plain launches and the application redone (same
+            // arithmetic)
             std::string why;
-            if (S.pc->timed_out(&why)) {
-                if (!S.pc->fallback_plain()) fail(KKT_ERR_HIP, why);
-                ++S.program_fallbacks;
-                S.info.program_fallbacks = S.program_fallbacks;
-                S.err = why + "; continued with plain launches";
+            if (S.pc_timed_out_agreed(&why)) {
+                if (!S.pc_fallback_plain(why)) fail(KKT_ERR_HIP, why);
                 S.pc_apply(dx.p, dy.p);
-                S.pc->check();
+                if (S.pc_timed_out_agreed(&why)) fail(KKT_ERR_HIP, why);
             }
         }
         down(S, dy.p, y);
@@ -314,6 +312,20 @@ int kkt_time_pc_sweeps(kkt_handle h, const double *d_x, double *d_y, float *ms, 
     KKT_TRY(h, {
         if (!d_x || !d_y || !ms || !launches || !phases) fail(KKT_ERR_ARG, "null argument");
         S.pc_apply_timed(d_x, d_y, ms, launches, phases);
+    });
+}
+
+int kkt_get_stage_times(kkt_handle h, kkt_stage_times *out) {
+    KKT_TRY(h, {
+        if (!out) fail(KKT_ERR_ARG, "null argument");
+        *out = S.stage_times;
+    });
+}
+
+int kkt_time_pc_stages(kkt_handle h, const double *d_x, double *d_y, kkt_pc_stage_times *out) {
+    KKT_TRY(h, {
+        if (!d_x || !d_y || !out) fail(KKT_ERR_ARG, "null argument");
+        S.pc_apply_timed_stages(d_x, d_y, out);
     });
 }
 

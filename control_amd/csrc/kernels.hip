@@ -2066,6 +2066,14 @@ void launch_norm2_finish(hipStream_t s, const double *dot, double *out) {
     hipLaunchKernelGGL(norm2_finish_kernel, dim3(1), dim3(1), 0, s, dot, out);
 }
 
+// the time-out word of the sweep programs as a summand of the Krylov all-reduce (time shards)
+__global__ void flag_to_double_kernel(const unsigned *flag, double *out) {
+    out[0] = (flag != nullptr && flag[0] != 0u) ? 1.0 : 0.0;
+}
+void launch_flag_to_double(hipStream_t s, const unsigned *flag, double *out) {
+    hipLaunchKernelGGL(flag_to_double_kernel, dim3(1), dim3(1), 0, s, flag, out);
+}
+
 template <int NV>
 __global__ __launch_bounds__(256) void maxpy_kernel(double *__restrict__ w, VecList V,
                                                     const double *__restrict__ coef,

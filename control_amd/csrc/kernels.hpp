@@ -3,7 +3,14 @@
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
+#include <string>
+
 namespace kkt {
+
+// thrown by launch_tile_sweep when a memset or the launch itself fails (never silently)
+struct TileLaunchError {
+    std::string msg;
+};
 
 constexpr int MAX_TERMS = 8;      // blocks summed into one block row by one launch
 constexpr int MDOT_MAX = 8;       // vectors per fused multi-dot / multi-axpy pass
@@ -196,6 +203,7 @@ void launch_mdot(hipStream_t s, const double *w, VecList V, int nv, int64_t n,
                  double *scratch, double *out);
 // out[0] = sqrt(<w, w> + extra) where extra = (add ? *add : 0)
 void launch_norm2_finish(hipStream_t s, const double *dot, double *out);
+void launch_flag_to_double(hipStream_t s, const unsigned *flag, double *out);
 // w += sign * sum_i coef[i] * V_i   (coef in device memory)
 void launch_maxpy(hipStream_t s, double *w, VecList V, const double *coef, double sign,
                   int nv, int64_t n);

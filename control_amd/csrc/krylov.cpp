@@ -9,6 +9,7 @@
 // device-to-host copy per iteration (the new Hessenberg column and the norm).
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <string>
 #include <vector>
 
@@ -25,7 +26,11 @@ void System::mdot(const double *w, const double *const *V, int nv, double *d_out
         for (int i = 0; i < m; ++i) L.v[i] = V[g + i];
         launch_mdot(stream, w, L, m, n_local, d_red_scratch, d_out + g);
     }
-    if (sharded) comm->allreduce_sum(d_out, nv, stream);
+    if (sharded) {
+        clock.mark(stream, StageClock::ORTH);
+        comm->allreduce_sum(d_out, nv, stream);
+        clock.mark(stream, StageClock::ALLREDUCE);
+    }
 }
 
 void System::norm2(const double *w, double *d_out) {
@@ -137,6 +142,43 @@ void System::pc_apply_timed(const double *d_x, double *d_y, float *ms, int *laun
     ns_project(pc->in(), d_x);
     pc->time_programs(ms, launches, phases);
     ns_pc_post(d_y, pc->out(), d_x);
+}
+
+void System::pc_apply_timed_stages(const double *d_x, double *d_y, kkt_pc_stage_times *out) {
+    if (!finalized) fail(KKT_ERR_STATE, "system not finalized");
+    if (!pc) fail(KKT_ERR_STATE, "no built-in preconditioner");
+    if (pc_stale) {
+        pc->values_changed();
+        pc_stale = false;
+    }
+    ns_project(pc->in(), d_x);
+    pc->time_stages(out);
+    ns_pc_post(d_y, pc->out(), d_x);
+}
+
+// The persistent sweep programs spin with a bound; a time-out leaves an error word on the device.
+// On time shards the decision to fall back must be the same on every rank (the preconditioner's
+// hand-offs and the Krylov all-reduces are collective): the flags are combined over the ranks.
+bool System::pc_timed_out_agreed(std::string *why) {
+    if (!pc) return false;
+    std::string local_why;
+    const bool local = pc->timed_out(&local_why);
+    bool any = local;
+    if (sharded && comm) any = comm->max_host(local ? 1.0 : 0.0, stream) > 0.5;
+    if (any && why)
+        *why = local ? local_why
+                     : std::string("persistent sweep kernel timed out on another rank of the time shard");
+    return any;
+}
+
+bool System::pc_fallback_plain(const std::string &why) {
+    if (!pc || !pc->fallback_plain()) return false;
+    ++program_fallbacks;
+    info.program_fallbacks = program_fallbacks;
+    err = why + "; continued with plain launches";
+    if (program_fallbacks == 1)
+        std::fprintf(stderr, "[kkt] %s\n", err.c_str());
+    return true;
 }
 
 namespace {
@@ -305,12 +347,16 @@ void System::solve(const double *d_b, double *d_u, int *its_out, int *reason_out
         u0 = d_guess;
         launch_copy(stream, u0, d_u, n_local);
     }
+    // the step-lock hook is consumed by this solve: its host arrays need not outlive it
+    struct LockGuard {
+        kkt_steplock &l;
+        ~LockGuard() { l = kkt_steplock{}; }
+    } lock_guard{steplock};
     try {
         solve_once(d_b, d_u, its_out, reason_out, rnorm_out, hist, hist_cap, hist_len);
     } catch (const ProgramTimeout &t) {
-        if (!pc || !pc->fallback_plain()) fail(KKT_ERR_HIP, t.why);
-        ++program_fallbacks;
-        err = t.why + "; continued with plain launches";
+        // (thrown on every rank of a time shard at the same point of the iteration)
+        if (!pc_fallback_plain(t.why)) fail(KKT_ERR_HIP, t.why);
         launch_copy(stream, d_u, u0, n_local);
         try {
             solve_once(d_b, d_u, its_out, reason_out, rnorm_out, hist, hist_cap, hist_len);
@@ -335,6 +381,21 @@ void System::solve_once(const double *d_b, double *d_u, int *its_out, int *reaso
     pc_cb_failed = false;
     info.last_pc_applies = 0;
     info.last_op_applies = 0;
+    {
+        const char *st = opt("stage_timers");
+        clock.on = st && st[0] == '1';
+    }
+    // operator / preconditioner applications bracketed by stage marks
+    auto apply = [&](const double *x, double *y) {
+        clock.mark(stream, StageClock::OTHER);
+        this->apply(x, y);
+        clock.mark(stream, StageClock::OP);
+    };
+    auto pc_apply = [&](const double *x, double *y) {
+        clock.mark(stream, StageClock::OTHER);
+        this->pc_apply(x, y);
+        clock.mark(stream, StageClock::PC);
+    };
     auto Vp = [&](int k) { return d_V + (size_t)k * vec_stride; };
     auto Zp = [&](int k) { return d_Z + (size_t)k * vec_stride; };
     auto read_scalars = [&](const double *d_src, int n) {
@@ -354,6 +415,7 @@ void System::solve_once(const double *d_b, double *d_u, int *its_out, int *reaso
 
     sync();
     const auto t_begin = std::chrono::steady_clock::now();
+    clock.begin(stream);
 
     // rnorm0 = norm of the (preconditioned) right-hand side
     double rnorm0;
@@ -421,6 +483,7 @@ void System::solve_once(const double *d_b, double *d_u, int *its_out, int *reaso
             // classical Gram-Schmidt: h = V^T w; w -= V h; tt = ||w||
             std::vector<const double *> Vl(it + 1);
             for (int k = 0; k <= it; ++k) Vl[k] = Vp(k);
+            clock.mark(stream, StageClock::OTHER);
             mdot(w, Vl.data(), it + 1, d_hcol);
             // the last update pass also leaves the partial sums of ||w||^2 (one pass over w
             // less; same chunks and summation order as mdot_stage1, so tt is bitwise the norm a
@@ -436,12 +499,29 @@ void System::solve_once(const double *d_b, double *d_u, int *its_out, int *reaso
                 else
                     launch_maxpy(stream, w, L, d_hcol + g, -1.0, mm, n_local);
             }
-            if (sharded) comm->allreduce_sum(d_tt + 1, 1, stream);
+            clock.mark(stream, StageClock::ORTH);
+            // time shards: the preconditioner's time-out word rides on this all-reduce, so that
+            // every rank sees a time-out of any rank in the same iteration
+            const unsigned *d_flag = (sharded && pc) ? pc->err_word() : nullptr;
+            if (sharded) {
+                launch_flag_to_double(stream, d_flag, d_tt + 2);
+                comm->allreduce_sum(d_tt + 1, 2, stream);
+                clock.mark(stream, StageClock::ALLREDUCE);
+            }
             launch_norm2_finish(stream, d_tt + 1, d_tt);
-            read_scalars(d_hcol, it + 2);
+            // (norm2_finish writes d_tt[0] and leaves d_tt[1]; the flag sits in d_tt[2])
+            read_scalars(d_hcol, it + 2 + (sharded ? 2 : 0));
             if (pc) {
                 std::string why;
-                if (pc->timed_out(&why)) throw ProgramTimeout{why};
+                if (sharded) {
+                    if (h_pinned[it + 3] > 0.0) {
+                        if (!pc->timed_out(&why))
+                            why = "persistent sweep kernel timed out on another rank of the time shard";
+                        throw ProgramTimeout{why};
+                    }
+                } else if (pc->timed_out(&why)) {
+                    throw ProgramTimeout{why};
+                }
             }
             for (int k = 0; k <= it; ++k) Hm(k, it) = h_pinned[k];
             const double tt = h_pinned[it + 1];
@@ -518,13 +598,18 @@ void System::solve_once(const double *d_b, double *d_u, int *its_out, int *reaso
     }
     // corrected solution (preconditioner.py:761-766)
     ns_project(d_u, d_u);
+    clock.mark(stream, StageClock::OTHER);
     sync();
     if (pc) {
         std::string why;
-        if (pc->timed_out(&why)) throw ProgramTimeout{why};
+        if (pc_timed_out_agreed(&why)) throw ProgramTimeout{why};
     }
     info.last_solve_ms =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    clock.finish(stage_times);
+    stage_times.iterations = its;
+    stage_times.operator_applies = info.last_op_applies;
+    stage_times.pc_applies = info.last_pc_applies;
     if (its_out) *its_out = its;
     if (reason_out) *reason_out = reason;
     if (rnorm_out) *rnorm_out = rn;

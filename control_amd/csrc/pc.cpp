@@ -117,6 +117,9 @@ void SchurPC::values_changed() {
     if (S_.opt("verbose") && d_.schur_emin <= 0)
         std::fprintf(stderr, "[kkt] Chebyshev sub-solves: degree %d; %lld Lanczos steps spent on "
                      "%zu matrices\n", schur_its_, (long long)spectrum_steps_, mats_.size());
+    S_.info.sweep_form = 0;
+    S_.info.sweep_tiles = S_.info.sweep_threads = S_.info.sweep_depth = S_.info.sweep_row_slots = 0;
+    S_.info.sweep_its = schur_its_;
     fuse_programs();
 }
 
@@ -329,8 +332,12 @@ bool SchurPC::prepare_tiles() {
     }
     TilePlan &tp = tile_plan_;
     if (!tp.symmetric || !tile_sweep_available(tp.W, tp.rpt, threads, tp.hslots)) return false;
-    const size_t lds = tile_sweep_lds_bytes(tp.nk_pad, std::max(schur_its_, 2));
+    // (solo levels of the stationary preconditioner run with mass_its, which may exceed schur_its_)
+    int max_its = std::max(schur_its_, 2);
+    for (const SweepLevel &lv : sweep_levels_) max_its = std::max(max_its, lv.its);
+    const size_t lds = tile_sweep_lds_bytes(tp.nk_pad, max_its);
     if (tp.ntiles > tile_sweep_max_tiles(tp.W, tp.rpt, threads, lds, tp.hslots)) return false;
+    tile_lds_checked_ = lds;
     tp.upload();
     const size_t words = 2 * (size_t)P.nrows;
     for (int i = 0; i < 4; ++i) {
@@ -362,6 +369,16 @@ bool SchurPC::fuse_tile_run(size_t k, size_t e, std::vector<PcStep> &out) {
     }
     if (run.empty()) return false;
     const int its = run[0]->its;
+    {
+        // residency and the dynamic-LDS attribute were checked for tile_lds_checked_ bytes
+        const size_t need = tile_sweep_lds_bytes(tile_plan_.nk_pad, its);
+        if (need > tile_lds_checked_) {
+            if (tile_plan_.ntiles > tile_sweep_max_tiles(tile_plan_.W, tile_plan_.rpt,
+                                                         tile_plan_.threads, need, tile_plan_.hslots))
+                return false;
+            tile_lds_checked_ = need;
+        }
+    }
     std::vector<TileLevel> levels;
     for (size_t i = 0; i < run.size(); ++i) {
         const SweepLevel &lv = *run[i];
@@ -557,6 +574,17 @@ void SchurPC::fuse_programs() {
         k = e;
     }
     steps_.swap(out);
+    // what runs, for the caller's records (kkt_info)
+    int form = 0;
+    for (const PcStep &s : steps_) {
+        if (s.kind == PcStep::TILE) form = 3;
+        if (s.kind == PcStep::PROG && form < 3) form = std::max(form, s.granule ? 2 : 1);
+    }
+    S_.info.sweep_form = form;
+    S_.info.sweep_tiles = form == 3 ? tile_plan_.ntiles : 0;
+    S_.info.sweep_threads = form == 3 ? tile_plan_.threads : 0;
+    S_.info.sweep_depth = form == 3 ? tile_plan_.depth : 0;
+    S_.info.sweep_row_slots = form == 3 ? tile_plan_.rpt : 0;
 }
 
 void SchurPC::debug_read(unsigned long long *out, int n) {
@@ -598,6 +626,51 @@ void SchurPC::time_programs(float *ms, int *launches, int64_t *phases) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
+}
+
+void PcBase::time_stages(kkt_pc_stage_times *out) {
+    // no itemisation: the whole application between two events
+    *out = kkt_pc_stage_times{};
+    fail(KKT_ERR_STATE, "kkt_time_pc_stages needs the built-in block-Schur preconditioner");
+}
+
+// One application step by step, an event after every step; a step's time goes to the sweeps
+// (persistent programs, or the single-block steps they replace), to the hand-offs between ranks,
+// or to the batched steps over all time levels.
+void SchurPC::time_stages(kkt_pc_stage_times *out) {
+    hipStream_t st = S_.stream;
+    *out = kkt_pc_stage_times{};
+    std::vector<hipEvent_t> ev(steps_.size() + 1);
+    for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipEventRecord(ev[0], st));
+    for (size_t k = 0; k < steps_.size(); ++k) {
+        replay(k, k + 1);
+        // (side-lane steps are rare -- option "lanes" -- and are charged to the step that waits)
+        HIPCHK(hipEventRecord(ev[k + 1], st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    for (size_t k = 0; k < steps_.size(); ++k) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+        const PcStep &s = steps_[k];
+        out->total_ms += ms;
+        if (s.kind == PcStep::PROG || s.kind == PcStep::TILE) {
+            out->sweeps_ms += ms;
+            out->sweep_launches += 1;
+            out->sweep_phases += s.nphases;
+        } else if (s.kind == PcStep::ROWS && s.rows.nops == 1 && n_ > 1) {
+            out->sweeps_ms += ms;          // a sweep step as a plain launch
+            out->sweep_launches += 1;
+            out->sweep_phases += 1;
+        } else if (s.kind == PcStep::COMM) {
+            out->comm_ms += ms;
+            out->comm_steps += 1;
+        } else {
+            out->batched_ms += ms;
+            if (s.kind == PcStep::ROWS || s.kind == PcStep::TIME) out->batched_launches += 1;
+        }
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
 }
 
 bool SchurPC::timed_out(std::string *why) {
@@ -1316,8 +1389,12 @@ void SchurPC::replay(size_t first, size_t last) {
                     // 3-D tiles (measured optima: 256^2 P1 24, 64^3 P1 48)
                     a.poll_delay = pd ? std::atoi(pd) : 24;
                 }
-                launch_tile_sweep(st, a, s.d_levels, tp.d_n, tp.d_grow, tp.d_lcol, tp.d_gpos, mask_,
-                                  tp.ntiles, tp.threads, words);
+                try {
+                    launch_tile_sweep(st, a, s.d_levels, tp.d_n, tp.d_grow, tp.d_lcol, tp.d_gpos,
+                                      mask_, tp.ntiles, tp.threads, words);
+                } catch (const TileLaunchError &e) {
+                    fail(KKT_ERR_HIP, e.msg);
+                }
                 break;
             }
             case PcStep::COMM:

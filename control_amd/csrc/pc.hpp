@@ -59,6 +59,10 @@ class PcBase {
     // plain launches (same arithmetic), so the caller can redo the work instead of failing.
     virtual bool timed_out(std::string *) { return false; }
     virtual bool fallback_plain() { return false; }
+    // device word that is non-zero after a time-out (null: this preconditioner has no programs)
+    virtual const unsigned *err_word() const { return nullptr; }
+    // one application replayed step by step with events (kkt_time_pc_stages)
+    virtual void time_stages(kkt_pc_stage_times *out);
     virtual void debug_read(unsigned long long *, int) {}
     // measurement: time the persistent programs of the next run() with events
     virtual void time_programs(float *ms, int *launches, int64_t *phases) {
@@ -80,6 +84,8 @@ class SchurPC : public PcBase {
     void check() override;   // throws if a persistent row program reported a time-out
     bool timed_out(std::string *why) override;
     bool fallback_plain() override;
+    const unsigned *err_word() const override { return d_err_; }
+    void time_stages(kkt_pc_stage_times *out) override;
     void debug_read(unsigned long long *out, int n) override;   // diagnostic builds (KKT_STAMPS)
     void time_programs(float *ms, int *launches, int64_t *phases) override;
     int bc_set() const { return bc_set_; }
@@ -162,6 +168,7 @@ class SchurPC : public PcBase {
     std::vector<SweepLevel> sweep_levels_;
     TilePlan tile_plan_;
     bool tile_tried_ = false, tile_ok_ = false;
+    size_t tile_lds_checked_ = 0;       // dynamic LDS bytes residency was checked for
     unsigned long long *d_tg_[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<void *> tile_owned_;    // coefficient tables of the current program
     uint32_t tile_epoch_cursor_ = 0;    // hand-off tags handed out to the launches of one application
@@ -235,6 +242,7 @@ class StokesPC : public PcBase {
     void check() override;
     bool timed_out(std::string *why) override { return inner_.pc && inner_.pc->timed_out(why); }
     bool fallback_plain() override { return inner_.pc && inner_.pc->fallback_plain(); }
+    const unsigned *err_word() const override { return inner_.pc ? inner_.pc->err_word() : nullptr; }
 
    private:
     System &S_, &inner_, &comm_;

@@ -25,10 +25,46 @@ void hip_check(hipError_t e, const char *what, const char *file, int line) {
 
 const char *System::opt(const char *key) const {
     auto it = options.find(key);
-    if (it != options.end()) return it->second.c_str();
-    std::string env = "KKT_";
-    for (const char *c = key; *c; ++c) env.push_back((char)std::toupper((unsigned char)*c));
-    return std::getenv(env.c_str());
+    return it != options.end() ? it->second.c_str() : nullptr;
+}
+
+// ---- stage clock: one event per mark; the interval since the previous mark belongs to `stage`
+void StageClock::begin(hipStream_t s) {
+    used = 0;
+    stage_of.clear();
+    if (!on) return;
+    mark(s, OTHER);
+}
+void StageClock::mark(hipStream_t s, int stage) {
+    if (!on) return;
+    if (used == pool.size()) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        pool.push_back(e);
+    }
+    HIPCHK(hipEventRecord(pool[used], s));
+    stage_of.push_back(stage);
+    ++used;
+}
+void StageClock::finish(kkt_stage_times &out) {
+    out = kkt_stage_times{};
+    if (!on || used < 2) return;
+    HIPCHK(hipEventSynchronize(pool[used - 1]));
+    double acc[NSTAGES] = {0, 0, 0, 0, 0};
+    for (size_t k = 1; k < used; ++k) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, pool[k - 1], pool[k]));
+        acc[stage_of[k]] += ms;
+    }
+    out.operator_ms = acc[OP];
+    out.pc_ms = acc[PC];
+    out.orth_ms = acc[ORTH];
+    out.allreduce_ms = acc[ALLREDUCE];
+    out.other_ms = acc[OTHER];
+    out.total_ms = acc[OP] + acc[PC] + acc[ORTH] + acc[ALLREDUCE] + acc[OTHER];
+}
+StageClock::~StageClock() {
+    for (hipEvent_t e : pool) (void)hipEventDestroy(e);
 }
 
 System::~System() {

@@ -124,6 +124,19 @@ struct KrylovCfg {
     int max_it = 1000;
 };
 
+// HIP events between the stages of a Krylov iteration (option "stage_timers"; kkt_get_stage_times)
+struct StageClock {
+    enum { OP = 0, PC = 1, ORTH = 2, ALLREDUCE = 3, OTHER = 4, NSTAGES = 5 };
+    bool on = false;
+    std::vector<hipEvent_t> pool;
+    std::vector<int> stage_of;     // stage of the interval that ends at event k (k >= 1)
+    size_t used = 0;
+    void begin(hipStream_t s);
+    void mark(hipStream_t s, int stage);
+    void finish(kkt_stage_times &out);   // synchronises on the last event
+    ~StageClock();
+};
+
 struct System {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -206,9 +219,11 @@ struct System {
 
     KrylovCfg ksp;
     kkt_steplock steplock{};   // test hook (kkt_debug_set_steplock); n_steps == 0: off
-    // execution options (kkt_set_option); a key that was never set falls back to the
-    // environment variable KKT_<KEY> (developer scripts), then to the built-in default
+    // execution options (kkt_set_option); a key that was never set has its built-in default
+    // (the library does not read the environment)
     std::map<std::string, std::string> options;
+    StageClock clock;
+    kkt_stage_times stage_times{};
     std::vector<double> tile_coords;   // kkt_set_tile_coordinates: N_x x tile_dim, or empty
     int tile_dim = 0;
     const char *opt(const char *key) const;
@@ -260,6 +275,12 @@ struct System {
     void solve_once(const double *d_b, double *d_u, int *its, int *reason, double *rnorm,
                     double *hist, int hist_cap, int *hist_len);
     int program_fallbacks = 0;   // sweep programs replaced by plain launches after a time-out
+    // a sweep program of the preconditioner timed out on ANY rank (collective on time shards)
+    bool pc_timed_out_agreed(std::string *why);
+    // ... then every rank rebuilds its preconditioner as plain launches (collective); false if
+    // there is nothing to fall back to
+    bool pc_fallback_plain(const std::string &why);
+    void pc_apply_timed_stages(const double *d_x, double *d_y, kkt_pc_stage_times *out);
     void solve_minres(const double *d_b, double *d_u, int *its, int *reason, double *rnorm,
                       double *hist, int hist_cap, int *hist_len);
     void ensure_workspace(int restart, bool flexible);

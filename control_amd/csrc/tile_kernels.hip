@@ -871,14 +871,23 @@ void launch_tile_sweep(hipStream_t s, const TileArgs &a, const TileLevel *d_leve
                        size_t granule_words) {
     if (a.nlevels <= 0 || ntiles <= 0) return;
     // tags of an earlier application must not match this one's hand-off numbers
+    auto chk = [](hipError_t e, const char *what) {
+        if (e != hipSuccess)
+            throw TileLaunchError{std::string("tile sweep program: ") + what + ": " +
+                                  hipGetErrorString(e)};
+    };
     if (a.clear)
         for (int i = 0; i < 2; ++i) {
-            (void)hipMemsetAsync(a.gnew[i], 0, granule_words * sizeof(unsigned long long), s);
-            (void)hipMemsetAsync(a.gold[i], 0, granule_words * sizeof(unsigned long long), s);
+            chk(hipMemsetAsync(a.gnew[i], 0, granule_words * sizeof(unsigned long long), s), "clearing the granule buffers");
+            chk(hipMemsetAsync(a.gold[i], 0, granule_words * sizeof(unsigned long long), s), "clearing the granule buffers");
         }
     const size_t lds = tile_sweep_lds_bytes(a.nk_pad, a.its);
-    hipLaunchKernelGGL(pick_tile(a.W, a.rpt, threads, a.fused_update != 0, a.hslots), dim3(ntiles), dim3(threads), lds, s, a, d_levels,
-                       d_n, d_grow, d_lcol, d_gpos, d_rowmask);
+    tile_fn f = pick_tile(a.W, a.rpt, threads, a.fused_update != 0, a.hslots);
+    if (!f) throw TileLaunchError{"tile sweep program: no kernel variant for this plan"};
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(f, dim3(ntiles), dim3(threads), lds, s, a, d_levels, d_n, d_grow, d_lcol,
+                       d_gpos, d_rowmask);
+    chk(hipGetLastError(), "launch");
 }
 
 }  // namespace kkt

@@ -34,6 +34,26 @@ def shard_range(m, rank, world):
     return lo.value, hi.value
 
 
+_uid_serial = [0]      # communicators created by this process (one rendezvous file each)
+
+
+def _watchdog(seconds, what):
+    """Bounded wait for a collective start-up that cannot be cancelled (ncclCommInitRank, the
+    first all-reduce): if it has not finished after `seconds`, say so and end this process
+    with a non-zero code instead of hanging the launcher."""
+    import sys
+    import threading
+
+    def fire():
+        print(f"[kkt] {what} did not finish within {seconds:.0f} s: giving up", file=sys.stderr,
+              flush=True)
+        os._exit(3)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 class _CommBase:
     def __init__(self, rank, world):
         self.rank, self.world = int(rank), int(world)
@@ -62,7 +82,10 @@ class RcclComm(_CommBase):
         os.makedirs(self._dir, exist_ok=True)
 
     def _exchange_id(self, lib):
-        path = os.path.join(self._dir, f"uid_{self._n_attached}")
+        # (numbered per process, not per object: a second transport object of the same launch
+        # must not find the first one's file)
+        path = os.path.join(self._dir, f"uid_{_uid_serial[0]}")
+        _uid_serial[0] += 1
         if self.rank == 0:
             buf = C.create_string_buffer(128)
             rc = lib.kkt_comm_unique_id(buf)
@@ -196,22 +219,27 @@ class GlooTransport:
 
 
 class RcclOrGloo(_CommBase):
-    """RCCL, checked when it is attached; if any rank could not bring it up (the ranks agree
-    over a gloo group of the launcher's rendezvous), every rank falls back to the host-staged
-    gloo transport and says so (``name``).  For launchers that must produce a measurement even
-    where RCCL does not start (``bench.py --gpus N``); a library user picks one transport."""
+    """RCCL, checked when it is attached (bounded wait); the ranks agree on the outcome over a
+    gloo group of the launcher's rendezvous.  If any rank could not bring RCCL up: with
+    ``allow_fallback`` every rank falls back to the host-staged gloo transport and says so
+    (``name``) -- the rehearsal with all ranks on one GPU, which RCCL refuses; without it every
+    rank raises, so that a multi-GPU run never silently measures the host-staged transport."""
 
-    def __init__(self, rank, world):
+    def __init__(self, rank, world, allow_fallback=False, timeout=180.0):
         super().__init__(rank, world)
-        self._rccl = RcclComm(rank, world)
+        self._rccl = RcclComm(rank, world, timeout=timeout)
         self._gloo = None
+        self._allow_fallback = allow_fallback
+        self._timeout = timeout
         self.name = "rccl"
 
     def _agree(self, ok):
+        import datetime
         import torch
         import torch.distributed as dist
         if not dist.is_initialized():
-            dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            dist.init_process_group("gloo", rank=self.rank, world_size=self.world,
+                                    timeout=datetime.timedelta(seconds=self._timeout))
         t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item() > 0.5)
@@ -221,6 +249,9 @@ class RcclOrGloo(_CommBase):
             self._gloo.attach(system)
             return
         why = ""
+        # ncclCommInitRank waits for every rank: if RCCL came up on some ranks only, it (or the
+        # first all-reduce) would wait for ever -- bounded by a watchdog that ends the process
+        dog = _watchdog(self._timeout, f"rank {self.rank}: RCCL start-up (ncclCommInitRank / first all-reduce)")
         try:
             self._rccl.attach(system)
             v = C.c_double(float(self.rank))
@@ -230,9 +261,18 @@ class RcclOrGloo(_CommBase):
                 why = f"max over ranks gave {v.value}"
         except Exception as e:                      # noqa: BLE001 -- any failure means fallback
             ok, why = False, f"{type(e).__name__}: {e}"
+        finally:
+            dog.cancel()
         if self._agree(ok):
             return
         import sys
+        if not self._allow_fallback:
+            print(f"[kkt] rank {self.rank}: RCCL transport not usable "
+                  f"({why or 'another rank failed'}); no fallback on distinct GPUs", file=sys.stderr,
+                  flush=True)
+            raise RuntimeError("RCCL did not start on every rank (the host-staged gloo transport is "
+                               "only used when all ranks share one GPU: KKT_DEVICE, or "
+                               "KKT_TRANSPORT=gloo)")
         print(f"[kkt] rank {self.rank}: RCCL transport not usable ({why or 'another rank failed'}); "
               "falling back to the host-staged gloo transport", file=sys.stderr, flush=True)
         tr = GlooTransport(self.rank, self.world)
@@ -242,12 +282,13 @@ class RcclOrGloo(_CommBase):
 
 
 def make_comm(rank, world, local_rank=0):
-    """Transport for ``bench.py`` under ``torch.distributed.run``: RCCL over xGMI (with the
-    gloo transport as the fallback if RCCL does not start), or the gloo rehearsal transport
-    outright when ``KKT_TRANSPORT=gloo``."""
+    """Transport for ``bench.py``: RCCL over xGMI.  When every rank is pinned to one GPU
+    (``KKT_DEVICE``, the one-GPU rehearsal) RCCL refuses and the ranks agree to fall back to the
+    host-staged gloo transport; ``KKT_TRANSPORT=gloo`` selects that transport outright.  On
+    distinct GPUs there is no fallback: a run whose RCCL does not start fails."""
     if os.environ.get("KKT_TRANSPORT", "rccl") == "gloo":
         tr = GlooTransport(rank, world)
         c = CallbackComm(rank, world, tr.allreduce, tr.sendrecv)
         c.name = "gloo"
         return c
-    return RcclOrGloo(rank, world)
+    return RcclOrGloo(rank, world, allow_fallback="KKT_DEVICE" in os.environ)

@@ -10,6 +10,7 @@ gfx950); this module only marshals.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -181,6 +182,13 @@ def _array_of(v, n, nx):
     return a.reshape(n, nx)
 
 
+# execution options a developer script may pass through the environment (forwarded by the mirror)
+_ENV_OPTION_KEYS = ("sell_r", "sell_sort", "no_graph", "persistent", "prog_mode", "prog_waves",
+                    "prog_steps", "tile_depth", "tile_waves", "lanes", "lane_chunks",
+                    "kernarg_ops", "shared_rows", "verbose", "stamps", "tile_poll_delay",
+                    "tile_unfused", "stage_timers")
+
+
 # ------------------------------------------------------------------ the block system
 class MultiBlockSystem:
     """GPU drop-in for ``preconditioner.py:216`` ``MultiBlockSystem``."""
@@ -213,7 +221,13 @@ class MultiBlockSystem:
         self._CN = bool(CN)
         self._comm = comm
         self._cb_keep = []
-        for key, value in (options or {}).items():     # kernel-form switches (kkt_set_option)
+        # kernel-form switches (kkt_set_option).  The library itself never reads the environment;
+        # developer scripts may still say KKT_<KEY>=value, which this mirror forwards as explicit
+        # calls (explicit `options` win; the debug_* hooks are never taken from the environment)
+        opts = {k: os.environ["KKT_" + k.upper()] for k in _ENV_OPTION_KEYS
+                if "KKT_" + k.upper() in os.environ}
+        opts.update(options or {})
+        for key, value in opts.items():
             self.set_option(key, value)
         self._ck(self._lib.kkt_set_layout(
             self._h, n_blocks_00, n_blocks_11, nx0, nx1, int(bool(CN)),

@@ -67,7 +67,7 @@ def stokes_problem(n=4, n_t=4, beta=1.0e-2, T=2.0, CN=False, share=True):
     return dict(th=th, tau=tau, beta=beta, n_t=n_t, CN=CN, m=bl["m"], blocks=bl)
 
 
-def stokes_gpu(p, specs=STOKES_SPECS, options=None, comm=None):
+def stokes_gpu(p, specs=STOKES_SPECS, options=None, comm=None, device=0):
     """Outer system, velocity KKT system and pressure commutator on the GPU + the StokesPC."""
     from .multiblock import (ChebSpec, ConstantNullspace, DirichletBCNullspace,
                              MultiBlockSystem, SchurPC, StokesPC)
@@ -77,17 +77,18 @@ def stokes_gpu(p, specs=STOKES_SPECS, options=None, comm=None):
     outer = MultiBlockSystem(th.n_v, th.n_p, *bl["outer"], n_blocks_00=2 * m,
                              n_blocks_11=2 * m, nullspace_0=(nsv,) * (2 * m),
                              nullspace_1=tuple(ConstantNullspace() for _ in range(2 * m)),
-                             CN=CN, options=options, comm=comm, shard_families=2, **kw)
+                             CN=CN, options=options, comm=comm, shard_families=2, device=device,
+                             **kw)
     inner = MultiBlockSystem(th.n_v, th.n_v, *bl["inner"], n_blocks_00=m, n_blocks_11=m,
                              nullspace_0=(nsv,) * m, nullspace_1=(nsv,) * m, CN=CN,
-                             options=options, comm=comm)
+                             options=options, comm=comm, device=device)
     if getattr(th, "coords_v", None) is not None and 2 * len(th.coords_v) == th.n_v:
         inner.set_tile_coordinates(np.vstack([th.coords_v, th.coords_v]))   # component-major
     # the commutator product is a plain block product (control.py:4625-4665): no transforms
     # (time-sharded with `comm`: the outer system by levels of its two block families, the
     # velocity and commutator systems by their levels -- the same [lo, hi) on a rank)
     commutator = MultiBlockSystem(th.n_p, th.n_p, *bl["commutator"], n_blocks_00=m,
-                                  n_blocks_11=m, options=options, comm=comm)
+                                  n_blocks_11=m, options=options, comm=comm, device=device)
     inner_pc = SchurPC(kind="CN" if CN else "BE", M=th.M_v, beta=p["beta"],
                        bc_nodes=th.boundary_v, mass=ChebSpec(*specs["mass"]),
                        schur=ChebSpec(*specs["schur"]), n_t=p["n_t"], tau=p["tau"])

@@ -84,9 +84,11 @@ const char *kkt_last_error(kkt_handle h);
  *   "prog_steps"  "0"            dataflow form without compact STEP records
  *   "tile_depth"  "1".."16"      SpMV steps per hand-off of the tile form (default: modelled)
  *   "tile_waves"  "1".."8"       waves per workgroup of the tile form (default 8)
+ *   "stage_timers" "1"           HIP events around the stages of every Krylov iteration
+ *                                (kkt_get_stage_times)
  *   "lanes", "lane_chunks", "kernarg_ops", "shared_rows", "verbose"   diagnostics
- * A key that was never set falls back to the environment variable KKT_<KEY> (developer
- * scripts), then to the default. */
+ * The library never reads the process environment: a key that was never set has its default.
+ * (The Python mirror forwards KKT_<KEY> variables of developer scripts as explicit calls.) */
 int kkt_set_option(kkt_handle h, const char *key, const char *value);
 
 /* Optional hint for the tile form of the preconditioner's sweep programs: coordinates of the
@@ -268,6 +270,29 @@ int kkt_time_pc_apply(kkt_handle h, const double *d_x, double *d_y, int reps, fl
 int kkt_time_pc_sweeps(kkt_handle h, const double *d_x, double *d_y, float *ms, int *launches,
                        int64_t *phases);
 
+/* Per-stage GPU time of the last kkt_solve* with gmres / fgmres (option "stage_timers" = "1"):
+ * HIP events on the library's stream between the stages of every iteration, summed over the
+ * solve.  operator = kkt_apply incl. its halo exchange; pc = Preconditioner.apply; orth =
+ * classical Gram-Schmidt (dots, updates, norm) without its all-reduces; allreduce = the
+ * all-reduces of the inner products (time-sharded handles; includes the wait for the slowest
+ * rank); other = residual set-up, normalisation, solution update, host round trips. */
+typedef struct kkt_stage_times {
+    double operator_ms, pc_ms, orth_ms, allreduce_ms, other_ms, total_ms;
+    int64_t iterations, operator_applies, pc_applies;
+} kkt_stage_times;
+int kkt_get_stage_times(kkt_handle h, kkt_stage_times *out);
+/* One application of the built-in block-Schur preconditioner replayed step by step with HIP
+ * events: sweeps = the persistent sweep programs (or, without them, the single-block steps of
+ * the time sweeps), batched = the steps over all time levels at once (mass solves, products,
+ * time transforms), comm = the hand-offs between ranks (time-sharded handles: includes the
+ * wait for the neighbour's pipeline stage).  Works on time-sharded handles (collective: every
+ * rank calls it).  Measurement only. */
+typedef struct kkt_pc_stage_times {
+    double sweeps_ms, batched_ms, comm_ms, total_ms;
+    int64_t sweep_launches, sweep_phases, batched_launches, comm_steps;
+} kkt_pc_stage_times;
+int kkt_time_pc_stages(kkt_handle h, const double *d_x, double *d_y, kkt_pc_stage_times *out);
+
 /* Step-locked parity hook (tests): while set, kkt_solve / kkt_solve_device with gmres or
  * fgmres replace their Krylov basis v_0 .. v_it by the caller's vectors before inner step `it`
  * of global step s (s < n_steps), and record what the step produced from them: the classical
@@ -276,7 +301,8 @@ int kkt_time_pc_sweeps(kkt_handle h, const double *d_x, double *d_y, float *ms, 
  * separate exponentially along a trajectory; single steps from identical inputs do not
  * (preconditioner.py:732-759 is third-party PETSc code: this pins the restatement step by step
  * against the CPU oracle).  V holds n_steps * (restart + 1) * n_local doubles; all arrays are
- * host memory owned by the caller and must stay valid until the hook is cleared (NULL). */
+ * host memory owned by the caller and must stay valid through the NEXT solve, which consumes
+ * the hook: it is cleared when that solve returns (or by passing NULL). */
 typedef struct kkt_steplock {
     int n_steps;
     int restart;
@@ -306,6 +332,11 @@ typedef struct kkt_info {
     int64_t program_fallbacks;  /* times a persistent sweep program timed out waiting for a
                                    neighbour workgroup and the preconditioner was rebuilt as
                                    plain launches (kkt_last_error holds the diagnostic record) */
+    /* how the time sweeps of the built-in preconditioner run (0 everywhere: none built yet) */
+    int64_t sweep_form;         /* 0 plain launches, 1 counter row program, 2 data-flow row
+                                   program, 3 tile program */
+    int64_t sweep_tiles, sweep_threads, sweep_depth, sweep_row_slots;   /* tile program plan */
+    int64_t sweep_its;          /* Chebyshev degree of the sub-solves (given or derived) */
 } kkt_info;
 int kkt_get_info(kkt_handle h, kkt_info *info);
 

@@ -148,3 +148,52 @@ def _picard_rank(rank, world, conns, out_q, CN):
     except Exception as e:
         import traceback
         out_q.put((rank, "error", traceback.format_exc() + repr(e)))
+
+
+def run_rank_timeout(rank, world, conns, out_q):
+    """A sweep program times out on ONE rank of a time shard (test hook: tile 0 of rank 0 skips a
+    hand-off).  The decision to fall back must be collective -- the time-out word rides on the
+    Krylov all-reduce -- or the ranks' sequences of all-reduces and hand-offs no longer match:
+    both ranks fall back once, restart together and reproduce the plain-launch solve bit for bit."""
+    try:
+        import common
+        from control_amd.dist import CallbackComm, PipeTransport, shard_range
+        p = common.heat_problem(n=96, n_t=12)      # six levels per rank: the hook's third hand-off exists
+        m, nx = p["m"], p["sd"].n_dofs
+        lo, hi = shard_range(m, rank, world)
+        tr = PipeTransport(rank, world, conns)
+        schur, mass = (6, 0.05, 2.1), (20, 0.5, 2.0)
+        b = common.rng_vector(2 * m * nx).reshape(2 * m, nx)
+        sp_ = {"linear_solver": "gmres", "gmres_restart": 10, "maximum_iterations": 8,
+               "relative_tolerance": 0.0, "absolute_tolerance": 0.0, "monitor_convergence": False,
+               "preconditioner": True}
+        out, its, falls, forms = [], [], [], []
+        for opts in ({"persistent": "0"},
+                     dict({"persistent": "1", "prog_mode": "tile"},
+                          **({"debug_drop_handoff": "3"} if rank == 0 else {}))):
+            comm = CallbackComm(rank, world, tr.allreduce, tr.sendrecv)
+            g = common.gpu_system(p, comm=comm, options=opts)
+            u0, u1 = np.zeros((hi - lo, nx)), np.zeros((hi - lo, nx))
+            r = g.solve(u0, u1, b[lo:hi].copy(), b[m + lo:m + hi].copy(), solver_parameters=sp_,
+                        pc_fn=common.gpu_pc(p, mass, schur))
+            out.append(np.vstack([u0, u1]))
+            its.append(r.its)
+            inf = g.info()
+            falls.append(int(inf["program_fallbacks"]))
+            forms.append(int(inf["sweep_form"]))
+            # and a single application through kkt_pc_apply on a fresh handle
+            if opts.get("persistent") == "1":
+                comm2 = CallbackComm(rank, world, tr.allreduce, tr.sendrecv)
+                g2 = common.gpu_system(p, comm=comm2, options=opts)
+                x = np.concatenate([b[lo:hi].ravel(), b[m + lo:m + hi].ravel()])
+                y_prog = g2.pc_apply(x, common.gpu_pc(p, mass, schur))
+                pc_falls = int(g2.info()["program_fallbacks"])
+            else:
+                x = np.concatenate([b[lo:hi].ravel(), b[m + lo:m + hi].ravel()])
+                y_plain = g.pc_apply(x, common.gpu_pc(p, mass, schur))
+        out_q.put((rank, "ok", dict(its=its, falls=falls, forms=forms, pc_falls=pc_falls,
+                                    same=bool(np.array_equal(out[0], out[1])),
+                                    pc_same=bool(np.array_equal(y_plain, y_prog)))))
+    except Exception as e:
+        import traceback
+        out_q.put((rank, "error", traceback.format_exc() + repr(e)))

@@ -96,6 +96,20 @@ def test_sharded_picard_loop_matches_one_rank(CN):
     assert res[0]["hist"] == res[1]["hist"]
 
 
+def test_sweep_program_timeout_on_one_rank_is_agreed_by_all():
+    """A time-out of a persistent sweep program on one rank only (drop hook on rank 0): every rank
+    falls back to plain launches in the same iteration and restarts; iteration counts equal,
+    results equal to the plain-launch run bit for bit, one fall-back counted on BOTH ranks -- in a
+    solve and in a single kkt_pc_apply."""
+    res = launch(2, False, "gmres", target="run_rank_timeout")
+    for r in range(2):
+        d = res[r]
+        assert d["its"] == [8, 8], d
+        assert d["falls"] == [0, 1], d            # plain run: none; program run: one, on both ranks
+        assert d["forms"] == [0, 0], d            # what runs after the fall-back: plain launches
+        assert d["same"] and d["pc_same"] and d["pc_falls"] == 1, d
+
+
 def test_rccl_transport_single_rank():
     """RCCL is loaded, a communicator is created and the collectives used by bench.py
     (barrier = all-reduce of one double, max) run -- world size 1, the only RCCL shape a
@@ -115,24 +129,55 @@ def test_rccl_transport_single_rank():
     assert v.value == 3.25
 
 
-def test_bench_two_ranks_on_one_gpu_falls_back_to_gloo():
-    """``bench.py --gpus 2`` exactly as the driver launches it (torch.distributed.run, one process
-    per rank), both ranks on GPU 0: RCCL refuses two ranks on one device, the ranks agree to
-    fall back to the host-staged gloo transport (control_amd.dist.RcclOrGloo), the sharded solve
-    converges in the single-GPU iteration count and the line says what ran."""
+def _bench_two_ranks(cmd_prefix, extra=()):
     import json
     import subprocess
     root = os.path.dirname(HERE)
     env = dict(os.environ, KKT_DEVICE="0", PYTHONUNBUFFERED="1")
-    env.pop("KKT_TRANSPORT", None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-config4", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=420)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    for k in ("KKT_TRANSPORT", "RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = cmd_prefix + [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup",
+                        "1", "--no-cpu-baseline"] + list(extra)
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads(out.stdout.strip().splitlines()[-1]), out.stderr
+
+
+def test_bench_two_ranks_on_one_gpu_falls_back_to_gloo():
+    """``bench.py --gpus 2`` exactly as the driver launches it (torch.distributed.run, one process
+    per rank), both ranks on GPU 0 (``KKT_DEVICE=0``, the rehearsal): RCCL refuses two ranks on
+    one device, the ranks agree to fall back to the host-staged gloo transport
+    (control_amd.dist.RcclOrGloo), the sharded solve converges in the single-GPU iteration count
+    and the line says what ran, stage by stage."""
+    line, err = _bench_two_ranks([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                  "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                  "--master-port", "29533"], ["--no-config4"])
     assert line["n_gpus"] == 2 and line["steps"] == 4
     assert line["config"]["transport"].startswith("gloo"), line["config"]["transport"]
     tts = line["config"]["time_to_solution"]
     assert tts["converged"] and tts["iterations"] == 40      # as on one GPU (profiles/r02)
-    assert "RCCL transport not usable" in out.stderr
+    assert "RCCL transport not usable" in err
+    st = line["stages"]
+    it = st["krylov_iteration_ms"]
+    assert it["preconditioner"] > it["operator"] > 0 and it["allreduce"] > 0, it
+    pcs = st["preconditioner_application_ms"]
+    assert pcs["time_sweeps"] > 0 and pcs["handoff_steps"] > 0 and pcs["rank_handoffs"] > 0, pcs
+    assert line["config"]["sweeps"]["program_fallbacks"] == 0
+
+
+def test_bench_self_launch_two_ranks_with_the_sharded_config4_and_stokes_legs():
+    """Plain ``python bench.py --gpus 2`` -- no launcher: the parent spawns the two ranks as fresh
+    children and relays rank 0's line -- including the side leg on BASELINE configs[3] (64^3 x 128)
+    time-sharded over the ranks; and ``--workload stokes2d`` sharded the same way (a small
+    instance)."""
+    line, _ = _bench_two_ranks([sys.executable])
+    assert line["n_gpus"] == 2 and line["config"]["transport"].startswith("gloo")
+    assert line["config"]["time_to_solution"]["iterations"] == 40
+    c4 = line["config4"]
+    assert "error" not in c4, c4
+    assert c4["n_gpus"] == 2 and c4["config"]["unknowns"] == 70304000
+    assert c4["config"]["time_to_solution"]["converged"]
+    assert c4["stages"]["preconditioner_application_ms"]["handoff_steps"] > 0
+    line, _ = _bench_two_ranks([sys.executable], ["--workload", "stokes2d", "--n", "16", "--n_t", "8"])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert line["stages"]["krylov_iteration_ms"]["preconditioner"] > 0
