@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkkt.so")
+# (KKT_LIB: another build of the same library, for same-box A/B measurements of a kernel change)
+LIB_PATH = os.environ.get("KKT_LIB") or os.path.join(_HERE, "libkkt.so")
 
 c_i32p = C.POINTER(C.c_int32)
 c_f64p = C.POINTER(C.c_double)
@@ -31,7 +32,7 @@ class PcDesc(C.Structure):
                 ("n_bc", C.c_int64), ("bc_idx", c_i32p),
                 ("mass_its", C.c_int), ("mass_emin", C.c_double), ("mass_emax", C.c_double),
                 ("schur_its", C.c_int), ("schur_emin", C.c_double),
-                ("schur_emax", C.c_double)]
+                ("schur_emax", C.c_double), ("schur_eimag", C.c_double)]
 
 
 class PcStokesDesc(C.Structure):

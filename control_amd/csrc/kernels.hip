@@ -345,6 +345,49 @@ __device__ __forceinline__ void accumulate_generic(const RowOp &op, const TermFn
             }
         }
     } else {
+#ifndef KKT_GENERIC_SERIAL
+        // Slices without a compile-time width (row-sorted P2 blocks: 9 or 19 entries, the
+        // rectangular divergence blocks): chunks of KC slots whose loads are all in flight
+        // together -- indices of a chunk, then its values and gathers, then the fma chain in slot
+        // order (the row's CSR order) -- with the next chunk's indices requested under the
+        // current chunk's gathers.  The slice width is wave-uniform, so the guards are scalar
+        // branches; slots past the width are not loaded at all.  (The serial loop below kept one
+        // index -> gather dependency in flight per slot: 3.5 TB/s on the Stokes operator.)
+        constexpr int KC = 10;
+        for (int t = 0; t < (w > 0 ? nterms : 0); ++t) {
+            const SpmvTerm tm = terms(t);
+            const gcd_p vp = (gcd_p)tm.vals + base;
+            const gcd_p x = resolve(tm.x, bases);
+            int c[KC][R];
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+                if (k < w) load_cols<R>(colp + (size_t)k * C, c[k]);
+            for (int k0 = 0; k0 < w; k0 += KC) {
+                double v[KC][R], xv[KC][R];
+                const int n = w - k0;       // live slots of this chunk (>= 1), wave-uniform
+#pragma unroll
+                for (int k = 0; k < KC; ++k)
+                    if (k < n) load_vals<R, NT>(vp + (size_t)(k0 + k) * C, v[k]);
+#pragma unroll
+                for (int k = 0; k < KC; ++k)
+                    if (k < n) {
+#pragma unroll
+                        for (int q = 0; q < R; ++q) xv[k][q] = ldv<COH>(x + c[k][q]);
+                    }
+                const int n1 = n - KC;      // live slots of the next chunk
+#pragma unroll
+                for (int k = 0; k < KC; ++k)
+                    if (k < n1) load_cols<R>(colp + (size_t)(k0 + KC + k) * C, c[k]);
+#pragma unroll
+                for (int k = 0; k < KC; ++k)
+                    if (k < n) {
+#pragma unroll
+                        for (int q = 0; q < R; ++q)
+                            acc[q] = __builtin_fma(v[k][q], xv[k][q], acc[q]);
+                    }
+            }
+        }
+#else
         for (int t = 0; t < nterms; ++t) {
             const SpmvTerm tm = terms(t);
             const gcd_p vp = (gcd_p)tm.vals + base;
@@ -360,6 +403,7 @@ __device__ __forceinline__ void accumulate_generic(const RowOp &op, const TermFn
                     acc[q] = __builtin_fma(v[q], ldv<COH>(x + c[q]), acc[q]);
             }
         }
+#endif
     }
 }
 
@@ -1892,6 +1936,52 @@ __global__ void time_transform_kernel(double *__restrict__ y, const double *__re
         }
     }
 }
+// T_1 / T_2 out of place, with the Dirichlet post-correction of the operator fused
+// (preconditioner.py:437-470 then 527-537): y_i = masked ? alpha * xin_i : t_i + t_{i+-1}.
+// One thread per (level, dof): the in-place form above walks the levels serially per dof (66 049
+// threads for 63 dependent loads each); raw rows `t` live in a buffer of their own, so every
+// output is independent and the pass runs at the HBM rate (16 B read, 8 B written per unknown).
+__global__ __launch_bounds__(256) void time_transform_mask_kernel(
+    double *__restrict__ y, const double *__restrict__ t, const double *__restrict__ xin,
+    const MaskJob *__restrict__ jobs, int kind, int n, int64_t nx,
+    const double *__restrict__ lo_halo, const double *__restrict__ hi_halo) {
+    const int i = blockIdx.y;
+    const MaskJob job = jobs[i];
+    const int64_t off = (int64_t)i * nx;
+    // 2 dofs per thread: 16-byte accesses
+    for (int64_t r = 2 * (blockIdx.x * (int64_t)blockDim.x + threadIdx.x); r < nx;
+         r += 2 * (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int64_t rr = r + q;
+            if (rr >= nx) break;
+            const double cur = t[off + rr];
+            double other = 0.0;
+            bool has;
+            if (kind == 1) {
+                has = (i + 1 < n) || hi_halo != nullptr;
+                if (i + 1 < n) other = t[off + nx + rr];
+                else if (hi_halo) other = hi_halo[rr];
+            } else {
+                has = i > 0 || lo_halo != nullptr;
+                if (i > 0) other = t[off - nx + rr];
+                else if (lo_halo) other = lo_halo[rr];
+            }
+            double v = has ? cur + other : cur;
+            if (job.mask != nullptr && job.mask[rr] != 0) v = job.alpha * xin[off + rr];
+            y[off + rr] = v;
+        }
+    }
+}
+void launch_time_transform_mask(hipStream_t s, double *y, const double *t, const double *xin,
+                                const MaskJob *d_jobs, int kind, int n, int64_t nx,
+                                const double *lo_halo, const double *hi_halo) {
+    if (n <= 0 || nx <= 0) return;
+    dim3 grid(grid_for((nx + 1) / 2, 256, 256), n);
+    hipLaunchKernelGGL(time_transform_mask_kernel, grid, dim3(256), 0, s, y, t, xin, d_jobs, kind,
+                       n, nx, lo_halo, hi_halo);
+}
+
 void launch_time_transform(hipStream_t s, double *y, const double *x, int kind, int n,
                            int64_t nx, const double *lo_halo, const double *hi_halo) {
     if (n <= 0 || nx <= 0) return;
@@ -2064,6 +2154,37 @@ __global__ void norm2_finish_kernel(const double *dot, double *out) {
 }
 void launch_norm2_finish(hipStream_t s, const double *dot, double *out) {
     hipLaunchKernelGGL(norm2_finish_kernel, dim3(1), dim3(1), 0, s, dot, out);
+}
+
+// symmetric and skew parts of a matrix on a structurally symmetric pattern: tpos[k] = position of
+// the transposed entry of position k (-1: padding).  *nonsym is set when a pair of stored entries
+// differs (pairs with an exact zero on one side are boundary columns zeroed by mask_columns: the
+// products they take part in are masked anyway).
+__global__ void vals_sym_skew_kernel(const double *__restrict__ a, const int32_t *__restrict__ tpos,
+                                     double *__restrict__ h, double *__restrict__ sk, int64_t n,
+                                     unsigned *__restrict__ nonsym) {
+    bool any = false;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t t = tpos[p];
+        const double x = a[p];
+        if (t < 0) {
+            h[p] = x;
+            sk[p] = 0.0;
+            continue;
+        }
+        const double y = a[t];
+        h[p] = 0.5 * (x + y);
+        sk[p] = 0.5 * (x - y);
+        if (x != 0.0 && y != 0.0 && fabs(x - y) > 1e-12 * (fabs(x) + fabs(y))) any = true;
+    }
+    if (any) atomicOr(nonsym, 1u);
+}
+void launch_vals_sym_skew(hipStream_t s, const double *a, const int32_t *tpos, double *h,
+                          double *sk, int64_t n, unsigned *nonsym) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(vals_sym_skew_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, tpos, h, sk, n,
+                       nonsym);
 }
 
 // the time-out word of the sweep programs as a summand of the Krylov all-reduce (time shards)

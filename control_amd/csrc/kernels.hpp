@@ -165,6 +165,8 @@ void launch_vals_axpy(hipStream_t s, double *out, const double *a, double c,
                       const double *b, int64_t n_padded);
 // *flag |= 1 when a and b differ in any bit
 void launch_vals_differ(hipStream_t s, const double *a, const double *b, int64_t n, unsigned *flag);
+void launch_vals_sym_skew(hipStream_t s, const double *a, const int32_t *tpos, double *h,
+                          double *sk, int64_t n, unsigned *nonsym);
 // dinv[r] = rowmask[r] ? 1 : 1 / diag(A)[r]
 void launch_extract_dinv(hipStream_t s, const int32_t *col, const int32_t *slice_off,
                          const double *vals, const uint8_t *rowmask, double *dinv,
@@ -179,6 +181,11 @@ void launch_axpby(hipStream_t s, double *y, double a, const double *x, double b,
 struct MaskJob { const uint8_t *mask; double alpha; };
 void launch_mask_blocks(hipStream_t s, double *y, const double *x, const double *mx,
                         const MaskJob *d_jobs, int nblocks, int64_t nx);
+// T_1 (kind 1) / T_2 (kind 2) from the raw rows `t` into `y` with the operator's Dirichlet
+// post-correction fused (d_jobs: the n blocks' masks, xin: the operator's input at the same offset)
+void launch_time_transform_mask(hipStream_t s, double *y, const double *t, const double *xin,
+                                const MaskJob *d_jobs, int kind, int n, int64_t nx,
+                                const double *lo_halo, const double *hi_halo);
 // CN time transforms over `n` consecutive blocks of length nx (block stride nx):
 // kind 1: T_1 (new_i = old_i + old_{i+1}); 2: T_2; 3: T_1^{-1}; 4: T_2^{-1}
 // (preconditioner.py:33-60, control.py:63-96).  `lo_halo`/`hi_halo` (may be null) stand

@@ -32,8 +32,8 @@ SchurPC::SchurPC(System &S, const kkt_pc_desc &d) : S_(S), d_(d) {
     // schur_its == -1: degree from the spectrum; schur_emin <= 0: interval from the spectrum
     if (d.mass_its < 0 || d.schur_its < -1) fail(KKT_ERR_ARG, "negative Chebyshev degree");
     if ((d.mass_its > 0 && !(d.mass_emax > d.mass_emin && d.mass_emin > 0)) ||
-        (d.schur_emin > 0 && !(d.schur_emax > d.schur_emin)))
-        fail(KKT_ERR_ARG, "Chebyshev bounds must satisfy 0 < emin < emax");
+        (d.schur_emin > 0 && !(d.schur_emax > d.schur_emin)) || d.schur_eimag < 0)
+        fail(KKT_ERR_ARG, "Chebyshev bounds must satisfy 0 < emin < emax, eimag >= 0");
     // deep copies: the caller's arrays are not kept (kkt.h conventions)
     m_indptr_.assign(d.m_indptr, d.m_indptr + nx_ + 1);
     m_indices_.assign(d.m_indices, d.m_indices + m_indptr_[nx_]);
@@ -767,6 +767,29 @@ void SchurPC::build() {
     values_changed();
 }
 
+// tpos[position of (r, c)] = position of (c, r) in the SELL value arrays of the preconditioner's
+// structure; null when some entry has no transposed partner (not a finite-element structure)
+const int32_t *SchurPC::transpose_positions() {
+    if (tpos_tried_) return d_tpos_;
+    tpos_tried_ = true;
+    const Pattern &P = S_.patterns[m_pat_];
+    if (P.nrows != P.ncols) return nullptr;
+    std::vector<int32_t> t((size_t)P.npadded, -1);
+    for (int64_t r = 0; r < P.nrows; ++r)
+        for (int32_t q = P.h_indptr[r]; q < P.h_indptr[r + 1]; ++q) {
+            const int32_t c = P.h_indices[q];
+            const int32_t *b = P.h_indices.data() + P.h_indptr[c];
+            const int32_t *e = P.h_indices.data() + P.h_indptr[c + 1];
+            const int32_t *hit = std::lower_bound(b, e, (int32_t)r);
+            if (hit == e || *hit != (int32_t)r) return nullptr;
+            t[(size_t)P.sell_index(r, q - P.h_indptr[r])] =
+                (int32_t)P.sell_index(c, (int)(hit - b));
+        }
+    d_tpos_ = dev_upload(t.data(), t.size());
+    owned_.push_back(d_tpos_);
+    return d_tpos_;
+}
+
 // base + c * M with bc rows/cols of `assemble(form, bcs=...)`, and its Jacobi diagonal
 SchurPC::Mat SchurPC::schur_matrix(const double *base_vals, double c) {
     uint64_t bits;
@@ -786,6 +809,7 @@ SchurPC::Mat SchurPC::schur_matrix(const double *base_vals, double c) {
     if (d_.schur_emin > 0) {
         m.emin = d_.schur_emin;
         m.emax = d_.schur_emax;
+        m.eimag = d_.schur_eimag > 0 ? d_.schur_eimag : 0.0;
     } else {
         // Interval from the matrix itself.  Matrices with the same shift and the same values
         // (mode G stores one copy per time level of a time-invariant operator) share one
@@ -804,17 +828,42 @@ SchurPC::Mat SchurPC::schur_matrix(const double *base_vals, double c) {
             if (!differ) {
                 m.emin = kv.second.emin;
                 m.emax = kv.second.emax;
+                m.eimag = kv.second.eimag;
                 found = true;
                 break;
             }
         }
         if (!found) {
-            const Spectrum sp = jacobi_spectrum(S_, m_pat_, m.vals, m.dinv, mask_, 400);
+            // Blocks with a convection term are not symmetric: the interval comes from the
+            // symmetric part H = (A + A^T) / 2 (Bendixson: Re lambda lies in the spectrum of
+            // D^-1/2 H D^-1/2) and the ellipse's imaginary semi-axis from the spectral radius of
+            // the skew part (|Im lambda| <= rho(D^-1/2 (A - A^T) / 2 D^-1/2)).
+            double *hv = nullptr, *sv2 = nullptr;
+            unsigned nonsym = 0;
+            const int32_t *tpos = transpose_positions();
+            if (tpos) {
+                hv = dev_alloc<double>(P.npadded);
+                sv2 = dev_alloc<double>(P.npadded);
+                unsigned *d_flag = dev_alloc<unsigned>(1);
+                HIPCHK(hipMemsetAsync(d_flag, 0, sizeof(unsigned), st));
+                launch_vals_sym_skew(st, m.vals, tpos, hv, sv2, P.npadded, d_flag);
+                HIPCHK(hipMemcpyAsync(&nonsym, d_flag, sizeof nonsym, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                HIPCHK(hipFree(d_flag));
+            }
+            const Spectrum sp = jacobi_spectrum(S_, m_pat_, nonsym ? hv : m.vals, m.dinv, mask_, 400);
             spectrum_steps_ += sp.steps;
             if (!(sp.emin > 0.0) || !(sp.emax > sp.emin))
                 fail(KKT_ERR_STATE, "sub-solve matrix is not positive definite: no Chebyshev interval");
             m.emin = 0.85 * sp.emin;      // Ritz values lie inside the spectrum
             m.emax = 1.05 * sp.emax;
+            if (nonsym) {
+                int steps = 0;
+                m.eimag = 1.1 * jacobi_skew_radius(S_, m_pat_, sv2, m.dinv, mask_, 40, &steps);
+                spectrum_steps_ += 2 * steps;
+            }
+            if (hv) (void)hipFree(hv);
+            if (sv2) (void)hipFree(sv2);
         }
     }
     mats_[key] = m;
@@ -951,7 +1000,8 @@ void SchurPC::emit_time(double *y, const double *x, int kind, int n, const doubl
 
 // KSPSolve_Chebyshev (first kind) + PCJACOBI, zero initial guess, exactly `its` steps
 // (options of control.py:1973-1982); its == 0: one Jacobi application (control.py:1984-1991).
-void SchurPC::emit_update_and_solve(Lin upd, const Solve &sv, int its, double emin, double emax) {
+void SchurPC::emit_update_and_solve(Lin upd, const Solve &sv, int its, double emin, double emax,
+                                    double eimag) {
     if (its == 0) {
         upd.y2 = sv.out;        // Jacobi: u = D^-1 b
         upd.dinv = sv.dinv;
@@ -965,7 +1015,7 @@ void SchurPC::emit_update_and_solve(Lin upd, const Solve &sv, int its, double em
     SweepLevel lv;
     lv.first = steps_.size();
     emit_lin({upd});
-    emit_solves({sv}, its, emin, emax, P_, nx_, true, &lv.coef);
+    emit_solves({sv}, its, emin, emax, P_, nx_, true, &lv.coef, eimag);
     lv.last = steps_.size();
     lv.its = its;
     // what the tile form can express: b = ca * sum_t U_t x + cy * b_in with one x
@@ -999,7 +1049,7 @@ void SchurPC::emit_update_and_solve(Lin upd, const Solve &sv, int its, double em
 
 void SchurPC::emit_solves(const std::vector<Solve> &sv, int its, double emin, double emax,
                           double *const P[3], int64_t pstride, bool first_done,
-                          std::vector<TileCoef> *coef_out) {
+                          std::vector<TileCoef> *coef_out, double eimag) {
     const size_t m = sv.size();
     // a single solve on a final right-hand side is a sweep level without update (the first
     // level of a sweep, the sub-solves of the stationary preconditioner)
@@ -1034,21 +1084,43 @@ void SchurPC::emit_solves(const std::vector<Solve> &sv, int its, double emin, do
         }
         emit_cheb(ops);
     }
+    // eimag > 0: the spectrum lies in the ellipse with centre d = (emax + emin) / 2 and semi-axes
+    // a = (emax - emin) / 2, eimag (blocks with a convection term).  Manteuffel's recurrence
+    // (Numer. Math. 28, 1977) for the same three-term sweep: alpha_1 = 2d / (2d^2 - c^2),
+    // alpha_n = 1 / (d - (c^2 / 4) alpha_{n-1}), beta_n = d alpha_n - 1 with c^2 = a^2 - eimag^2,
+    // which may be negative -- only c^2 enters, the arithmetic stays real.  Restated in the
+    // oracle (chebyshev_ellipse_coefficients); for eimag == 0 PETSc's form below is kept, bit
+    // for bit what rounds 1 and 2 ran.
+    const double ell_d = 0.5 * (emax + emin), ell_a = 0.5 * (emax - emin);
+    const double ell_c2 = ell_a * ell_a - eimag * eimag;
+    double ell_alpha = 1.0 / ell_d;
     for (int step = 2; step <= its; ++step) {
-        const double c_kp1 = 2.0 * mu * c_k - c_km1;
-        const double omega = omegaprod * c_k / c_kp1;
+        double k1, k2, k3;
+        if (eimag > 0.0) {
+            ell_alpha = 1.0 / (ell_d - (step == 2 ? 0.5 : 0.25) * ell_c2 * ell_alpha);
+            const double beta = ell_d * ell_alpha - 1.0;
+            k1 = -beta;
+            k2 = 1.0 + beta;
+            k3 = ell_alpha;
+        } else {
+            const double c_kp1 = 2.0 * mu * c_k - c_km1;
+            const double omega = omegaprod * c_k / c_kp1;
+            k1 = 1.0 - omega;
+            k2 = omega;
+            k3 = scale * omega;
+            c_km1 = c_k;
+            c_k = c_kp1;
+        }
         const bool last = step == its;
         for (size_t q = 0; q < m; ++q) {
             const double *pk = target(step - 1, q);
             const double *pkm1 = step >= 3 ? target(step - 2, q) : nullptr;
             ops[q] = Cheb{sv[q].vals, sv[q].dinv, sv[q].b, pk, pkm1, target(step, q),
-                          1.0 - omega, omega, scale * omega,
+                          k1, k2, k3,
                           last ? sv[q].post1 : 1.0, last ? sv[q].post2 : 1.0};
         }
-        if (coef_out) coef_out->push_back(TileCoef{1.0 - omega, omega, scale * omega});
+        if (coef_out) coef_out->push_back(TileCoef{k1, k2, k3});
         emit_cheb(ops);
-        c_km1 = c_k;
-        c_k = c_kp1;
     }
     if (record_solo) {
         solo.last = steps_.size();
@@ -1079,9 +1151,9 @@ void SchurPC::build_stationary() {
     emit_lin({Lin{{Term{Dv, u0}}, B_, 1.0, 0.0, -1.0, nullptr, b1}});
     Mat S1 = schur_matrix(Dv, c), S2 = schur_matrix(Dz, c);
     schur_its_ = resolve_its(S1);
-    emit_solves({Solve{S1.vals, S1.dinv, B_, u1}}, schur_its_, S1.emin, S1.emax, P_, nx_);
+    emit_solves({Solve{S1.vals, S1.dinv, B_, u1}}, schur_its_, S1.emin, S1.emax, P_, nx_, false, nullptr, S1.eimag);
     emit_lin({Lin{{Term{m_vals_, u1}}, B_, 1.0}});
-    emit_solves({Solve{S2.vals, S2.dinv, B_, u1}}, schur_its_, S2.emin, S2.emax, P_, nx_);
+    emit_solves({Solve{S2.vals, S2.dinv, B_, u1}}, schur_its_, S2.emin, S2.emax, P_, nx_, false, nullptr, S2.eimag);
 }
 
 // Time sharding: a rank owns blocks [lo, hi).  Everything that is independent
@@ -1158,9 +1230,9 @@ void SchurPC::build_BE() {
                 emit_update_and_solve(Lin{{Term{block_vals(KKT_Q10, i, i - 1),
                                                 i - 1 >= lo ? blk(u1, i - 1) : h_u1_}},
                                           blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i), nullptr},
-                                      sv, schur_its_, F.emin, F.emax);
+                                      sv, schur_its_, F.emin, F.emax, F.eimag);
             else
-                emit_solves({sv}, schur_its_, F.emin, F.emax, P_, nx_);
+                emit_solves({sv}, schur_its_, F.emin, F.emax, P_, nx_, false, nullptr, F.eimag);
         }
     };
     if (lanes) {
@@ -1196,9 +1268,9 @@ void SchurPC::build_BE() {
             emit_update_and_solve(Lin{{Term{block_vals(KKT_Q01, i, i + 1),
                                             i + 1 < hi ? blk(u1, i + 1) : h_u1_}},
                                       blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i), nullptr},
-                                  sv, schur_its_, G.emin, G.emax);
+                                  sv, schur_its_, G.emin, G.emax, G.eimag);
         else
-            emit_solves({sv}, schur_its_, G.emin, G.emax, P_, nx_);
+            emit_solves({sv}, schur_its_, G.emin, G.emax, P_, nx_, false, nullptr, G.eimag);
     }
     if (dn >= 0) emit_comm(blk(u1, lo), dn, nullptr, -1);
 }
@@ -1268,9 +1340,9 @@ void SchurPC::build_CN() {
             emit_update_and_solve(Lin{{Term{block_vals(KKT_Q10, i, i - 1), prev},
                                        Term{cM.vals, prev}},
                                       blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i), nullptr},
-                                  sv, schur_its_, F.emin, F.emax);
+                                  sv, schur_its_, F.emin, F.emax, F.eimag);
         } else {
-            emit_solves({sv}, schur_its_, F.emin, F.emax, P_, nx_);
+            emit_solves({sv}, schur_its_, F.emin, F.emax, P_, nx_, false, nullptr, F.eimag);
         }
     }
     if (up >= 0) emit_comm(blk(u1, hi - 1), up, nullptr, -1);
@@ -1291,9 +1363,9 @@ void SchurPC::build_CN() {
             Mat H = schur_matrix(block_vals(KKT_Q01, i, i + 1), c);
             emit_update_and_solve(Lin{{Term{H.vals, i + 1 < hi ? blk(u1, i + 1) : h_u1_}},
                                       blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i), nullptr},
-                                  sv, schur_its_, G.emin, G.emax);
+                                  sv, schur_its_, G.emin, G.emax, G.eimag);
         } else {
-            emit_solves({sv}, schur_its_, G.emin, G.emax, P_, nx_);
+            emit_solves({sv}, schur_its_, G.emin, G.emax, P_, nx_, false, nullptr, G.eimag);
         }
     }
     if (dn >= 0) emit_comm(blk(u1, lo), dn, nullptr, -1);

@@ -21,6 +21,10 @@ struct Spectrum {
 };
 Spectrum jacobi_spectrum(System &S, int pattern, const double *vals, const double *dinv,
                          const uint8_t *rowmask, int max_steps);
+// spectral radius of D^-1 S for the values `skew_vals` of a skew-symmetric matrix on `pattern`
+// (power iteration on -(D^-1 S)^2; an estimate from below)
+double jacobi_skew_radius(System &S, int pattern, const double *skew_vals, const double *dinv,
+                          const uint8_t *rowmask, int max_steps, int *steps_out);
 
 struct PcStep {
     enum Kind { ROWS, TIME, COPY, COMM, PROG, TILE, EV_RECORD, EV_WAIT } kind;
@@ -117,6 +121,7 @@ class SchurPC : public PcBase {
         double *vals;
         double *dinv;
         double emin = 0.0, emax = 0.0;   // Chebyshev interval of this matrix (given or estimated)
+        double eimag = 0.0;              // > 0: imaginary semi-axis of the spectrum's ellipse
     };
     int schur_its_ = 0;                  // degree of the sub-solves (given or derived)
     double typical_emin_ = 0.0, typical_emax_ = 0.0;
@@ -213,10 +218,16 @@ class SchurPC : public PcBase {
     };
     void emit_solves(const std::vector<Solve> &sv, int its, double emin, double emax,
                      double *const P[3], int64_t pstride, bool first_done = false,
-                     std::vector<TileCoef> *coef_out = nullptr);
+                     std::vector<TileCoef> *coef_out = nullptr, double eimag = 0.0);
     // the sweep step "b -= A u_prev (masked), then solve": the update and the first
     // Chebyshev step share one launch
-    void emit_update_and_solve(Lin upd, const Solve &sv, int its, double emin, double emax);
+    void emit_update_and_solve(Lin upd, const Solve &sv, int its, double emin, double emax,
+                               double eimag = 0.0);
+    // position of the transposed entry of every stored entry of the preconditioner's sparsity
+    // structure (device array, built on first use; null when the structure is not symmetric)
+    const int32_t *transpose_positions();
+    int32_t *d_tpos_ = nullptr;
+    bool tpos_tried_ = false;
     void push_rows(std::vector<RowOp> &r);
     void build_stationary();
     void build_BE();

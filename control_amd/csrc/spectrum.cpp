@@ -193,4 +193,90 @@ Spectrum jacobi_spectrum(System &S, int pattern, const double *vals, const doubl
     return out;
 }
 
+// rho(D^-1 S) for a skew-symmetric S (the convection part of a sub-solve matrix): its eigenvalues
+// are +- i mu_j, so (D^-1 S)^2 is similar to a negative semi-definite matrix with eigenvalues
+// -mu_j^2; power iteration v <- (D^-1 S)^2 v, mu^2 ~ ||(D^-1 S)^2 v|| / ||v||.  Two SpMVs and one
+// reduction per step; the estimate approaches mu_max from below (the caller widens it).
+double jacobi_skew_radius(System &S, int pattern, const double *skew_vals, const double *dinv,
+                          const uint8_t *rowmask, int max_steps, int *steps_out) {
+    const Pattern &P = S.patterns[pattern];
+    const int64_t n = P.nrows;
+    hipStream_t st = S.stream;
+    auto vec = [&]() {
+        double *p = dev_alloc<double>(n + 32);
+        HIPCHK(hipMemsetAsync(p, 0, (n + 32) * sizeof(double), st));
+        return p;
+    };
+    double *v = vec(), *z = vec();
+    double *scratch = dev_alloc<double>((size_t)REDUCE_BLOCKS * MDOT_MAX);
+    double *d_out = dev_alloc<double>(4);
+    {
+        std::vector<double> h(n);
+        uint64_t sd = 0x2545f4914f6cdd1dull;
+        for (int64_t i = 0; i < n; ++i) {
+            sd = sd * 6364136223846793005ull + 1442695040888963407ull;
+            h[i] = (double)(sd >> 11) / (double)(1ull << 53) - 0.5;
+        }
+        if (rowmask) {
+            std::vector<uint8_t> m(n);
+            HIPCHK(hipMemcpy(m.data(), rowmask, n, hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < n; ++i)
+                if (m[i]) h[i] = 0.0;
+        }
+        HIPCHK(hipMemcpy(v, h.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    auto vabs = [](const double *q) { return q ? VRef{(int64_t)(uintptr_t)q, 0, 0} : VRef{0, -1, 0}; };
+    // y = -D^-1 (0 - S x): the Chebyshev epilogue with c3 = -1 and no right-hand side
+    RowOp op{};
+    op.col = P.d_col;
+    op.perm = P.d_perm;
+    op.slice_off = P.d_slice_off;
+    op.uniform_w = P.uniform_w;
+    op.nrows = (int32_t)n;
+    op.nslices = P.nslices;
+    op.nterms = 1;
+    op.mode = EPI_CHEB;
+    op.t[0].vals = skew_vals;
+    op.y2 = op.yin = op.z = op.mx = op.b = op.pk = op.pkm1 = vabs(nullptr);
+    op.dinv = dinv;
+    op.c1 = op.c2 = 0.0;
+    op.c3 = -1.0;
+    op.post1 = op.post2 = 1.0;
+    op.rowmask = rowmask;
+    RowOp both[2] = {op, op};
+    both[0].t[0].x = vabs(v);
+    both[0].y = vabs(z);
+    both[1].t[0].x = vabs(z);
+    both[1].y = vabs(v);
+    RowOp *d_ops = dev_upload(both, 2);
+    const Bases B{{nullptr, nullptr, nullptr, nullptr}};
+    double host[2];
+    auto norm = [&](const double *a) {
+        VecList L{};
+        L.v[0] = a;
+        launch_mdot(st, a, L, 1, n, scratch, d_out);
+        HIPCHK(hipMemcpyAsync(host, d_out, sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return std::sqrt(host[0]);
+    };
+    double nv = norm(v), mu2 = 0.0, last = -1.0;
+    int k = 0;
+    for (; k < max_steps && nv > 0.0 && std::isfinite(nv); ++k) {
+        launch_axpby(st, v, 0.0, z, 1.0 / nv, n);      // v /= ||v||
+        launch_rowops(st, d_ops, 1, P.nslices, P.R, B, 1, P.uniform_w);       // z = D^-1 S v
+        launch_rowops(st, d_ops + 1, 1, P.nslices, P.R, B, 1, P.uniform_w);   // v = D^-1 S z
+        nv = norm(v);
+        mu2 = nv;
+        if (k >= 8 && std::fabs(mu2 - last) <= 0.005 * mu2) {
+            ++k;
+            break;
+        }
+        last = mu2;
+    }
+    if (steps_out) *steps_out = k;
+    for (double *q : {v, z, scratch, d_out}) (void)hipFree(q);
+    (void)hipFree(d_ops);
+    return (mu2 > 0.0 && std::isfinite(mu2)) ? std::sqrt(mu2) : 0.0;
+}
+
 }  // namespace kkt

@@ -872,7 +872,15 @@ void System::apply(const double *d_x, double *d_y) {
         HIPCHK(hipEventRecord(ev_x_ready, stream));
         HIPCHK(hipStreamWaitEvent(comm_stream, ev_x_ready, 0));
     }
-    Bases B{{xin, d_y, d_halo_x0_lo, d_halo_x1_hi}};
+    // Crank-Nicolson: the block rows leave the raw rows rho in a buffer of their own; the time
+    // transform then writes y from it, every (level, dof) independently, with the Dirichlet
+    // post-correction fused (one pass instead of a serial in-place transform and a mask pass)
+    double *rows_out = d_y;
+    if (CN) {
+        if (!d_tmp_y) d_tmp_y = new_vec();
+        rows_out = d_tmp_y;
+    }
+    Bases B{{xin, rows_out, d_halo_x0_lo, d_halo_x1_hi}};
     auto launch = [&](const RowLaunch &L) {
         if (L.ngroups > 0 &&
             launch_rowops_grouped(stream, L.d_ops, L.d_groups, L.ngroups, L.max_slices, L.R,
@@ -900,21 +908,23 @@ void System::apply(const double *d_x, double *d_y) {
     }
     for (size_t w = (size_t)first_halo_launch; w < apply_launches.size(); ++w) launch(apply_launches[w]);
     if (CN) {
-        if (sharded) comm_exchange_row_halos(*this, d_y);
+        if (sharded) comm_exchange_row_halos(*this, rows_out);
         for (const TimeGroup &g : time_groups) {
-            double *yb = d_y + (g.first_local_block < n0_loc
+            const int64_t off = g.first_local_block < n0_loc
                                     ? (int64_t)g.first_local_block * nx0
                                     : (int64_t)n0_loc * nx0 +
-                                          (int64_t)(g.first_local_block - n0_loc) * nx1);
+                                          (int64_t)(g.first_local_block - n0_loc) * nx1;
             const double *lo_h = nullptr, *hi_h = nullptr;
             if (sharded) {
                 if (g.kind == 1 && hi < mf) hi_h = g.d_halo;
                 if (g.kind == 2 && lo > 0) lo_h = g.d_halo;
             }
-            launch_time_transform(stream, yb, yb, g.kind, g.n, g.nx, lo_h, hi_h);
+            // y = P T rho + alpha (I - P) x (preconditioner.py:437-470, 527-537)
+            launch_time_transform_mask(stream, d_y + off, rows_out + off, d_x + off,
+                                       d_mask_jobs + g.first_local_block, g.kind, g.n, g.nx, lo_h,
+                                       hi_h);
         }
-    }
-    if (!fused_row_masks) {
+    } else if (!fused_row_masks) {
         // y = P y + alpha (I - P) x on Dirichlet blocks (preconditioner.py:527-537)
         if (nx0 == nx1) {
             launch_mask_blocks(stream, d_y, d_y, d_x, d_mask_jobs, nb, nx0);

@@ -70,10 +70,14 @@ class FullNullspace(Nullspace):
 # ------------------------------------------------------------------- preconditioner
 @dataclass
 class ChebSpec:
-    """``its`` Jacobi-Chebyshev steps on ``[emin, emax]``; ``its == 0``: one Jacobi step."""
+    """``its`` Jacobi-Chebyshev steps on ``[emin, emax]``; ``its == 0``: one Jacobi step.
+    ``eimag > 0`` (Schur sub-solves only): the spectrum lies in the ellipse around the
+    interval's mid-point with that imaginary semi-axis (blocks with a convection term);
+    ``its = -1`` / ``emin <= 0``: degree / ellipse estimated per matrix on the device."""
     its: int
     emin: float = 0.0
     emax: float = 0.0
+    eimag: float = 0.0
 
 
 @dataclass
@@ -388,7 +392,8 @@ class MultiBlockSystem:
                 m_values=data.ctypes.data_as(_lib.c_f64p), n_bc=len(bc), bc_idx=pbc,
                 mass_its=int(pc_fn.mass.its), mass_emin=float(pc_fn.mass.emin),
                 mass_emax=float(pc_fn.mass.emax), schur_its=int(pc_fn.schur.its),
-                schur_emin=float(pc_fn.schur.emin), schur_emax=float(pc_fn.schur.emax))
+                schur_emin=float(pc_fn.schur.emin), schur_emax=float(pc_fn.schur.emax),
+                schur_eimag=float(getattr(pc_fn.schur, "eimag", 0.0)))
             self._ck(self._lib.kkt_set_pc_schur(self._h, C.byref(d)))
             self._pc_state = pc_fn
         elif isinstance(pc_fn, StokesPC):

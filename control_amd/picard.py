@@ -146,7 +146,7 @@ class GpuLinearSolver:
     values of the blocks that carry the re-linearised operator."""
 
     def __init__(self, pb: NavierStokesControl, *, mass, schur, kp, mp, solver_parameters,
-                 device=0, comm=None, host_allreduce=None):
+                 device=0, comm=None, host_allreduce=None, options=None):
         """``comm`` (``control_amd.dist``): the three systems are time-sharded (BASELINE
         configs[4] names 8 GPUs) -- every rank runs the same Picard loop on the whole iterate
         (residual and re-linearisation are host work on replicated data, as cheap as in the
@@ -154,6 +154,7 @@ class GpuLinearSolver:
         and the shards are summed into the whole update with ``host_allreduce(array, op)``
         (in place over ranks, op 0 = sum: e.g. ``GlooTransport.allreduce``)."""
         self.pb, self.device = pb, device
+        self.options = options          # execution options of the three systems (kkt_set_option)
         self.specs = dict(mass=mass, schur=schur, kp=kp, mp=mp)
         self.solver_parameters = solver_parameters
         self.outer = None
@@ -178,15 +179,16 @@ class GpuLinearSolver:
             th.n_v, th.n_p, *bl["outer"], n_blocks_00=2 * m, n_blocks_11=2 * m,
             nullspace_0=(nsv,) * (2 * m),
             nullspace_1=tuple(ConstantNullspace() for _ in range(2 * m)), device=self.device,
-            CN=pb.CN, comm=self.dist, shard_families=2, **kw)
+            CN=pb.CN, comm=self.dist, shard_families=2, options=self.options, **kw)
         self.inner = MultiBlockSystem(th.n_v, th.n_v, *bl["inner"], n_blocks_00=m,
                                       n_blocks_11=m, nullspace_0=(nsv,) * m,
                                       nullspace_1=(nsv,) * m, device=self.device, CN=pb.CN,
-                                      comm=self.dist)
+                                      comm=self.dist, options=self.options)
         if getattr(th, "coords_v", None) is not None and 2 * len(th.coords_v) == th.n_v:
             self.inner.set_tile_coordinates(np.vstack([th.coords_v, th.coords_v]))
         self.comm = MultiBlockSystem(th.n_p, th.n_p, *bl["commutator"], n_blocks_00=m,
-                                     n_blocks_11=m, device=self.device, comm=self.dist)
+                                     n_blocks_11=m, device=self.device, comm=self.dist,
+                                     options=self.options)
         s = self.specs
         inner_pc = SchurPC(kind="CN" if pb.CN else "BE", M=th.M_v, beta=pb.beta, bc_nodes=th.boundary_v,
                            mass=ChebSpec(*s["mass"]), schur=ChebSpec(*s["schur"]), n_t=pb.n_t,

@@ -163,7 +163,10 @@ enum { KKT_PC_STATIONARY = 0, KKT_PC_INSTATIONARY_BE = 1, KKT_PC_INSTATIONARY_CN
  * `mass_its` Jacobi-Chebyshev steps on [mass_emin, mass_emax] (control.py:1967-1982;
  * mass_its == 0: one Jacobi application, control.py:1984-1991).  The hypre sub-solves of
  * the reference are replaced by `schur_its` Jacobi-Chebyshev steps on
- * [schur_emin, schur_emax] (BASELINE.json north_star). */
+ * [schur_emin, schur_emax] (BASELINE.json north_star).  A hand-set interval much wider than the
+ * spectrum is harmless for symmetric blocks and harmful for blocks with convection: outside the
+ * interval's ellipse the Chebyshev polynomial grows with the imaginary part, and a wide interval
+ * has a weak normalisation -- give the matrix's own bounds (or let the library estimate them). */
 typedef struct kkt_pc_desc {
     int kind;            /* KKT_PC_* */
     int n_t;             /* time levels (ignored for STATIONARY) */
@@ -181,6 +184,14 @@ typedef struct kkt_pc_desc {
     int schur_its;       /* -1: 1.6 sqrt(emax / emin) of a typical time level's matrix */
     double schur_emin, schur_emax;   /* schur_emin <= 0: per matrix, from a Lanczos estimate of its
                                         Jacobi-scaled spectrum on the device (spectrum.cpp) */
+    double schur_eimag;  /* > 0: the Jacobi-scaled spectrum of the sub-solve matrices lies in the
+                            ellipse with real semi-axis (schur_emax - schur_emin) / 2 and imaginary
+                            semi-axis schur_eimag around their mid-point (forward operators with a
+                            convection term, control.py:1887-1896: the blocks are not symmetric);
+                            the sweeps keep their three-term form with the coefficients of that
+                            ellipse (Manteuffel 1977).  0: real interval.  With schur_emin <= 0 it
+                            is estimated per matrix too (symmetric part for the interval, spectral
+                            radius of the skew part for the semi-axis). */
 } kkt_pc_desc;
 
 int kkt_set_pc_schur(kkt_handle h, const kkt_pc_desc *desc);

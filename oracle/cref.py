@@ -149,7 +149,7 @@ class CRef:
         pc.Fdinv, pc.Gdinv = fd, gd
         pc.mask = mask.ctypes.data_as(u8p)
         pc.mass_its, pc.mass_emin, pc.mass_emax = mass
-        pc.schur_its, pc.schur_emin, pc.schur_emax = schur
+        pc.schur_its, pc.schur_emin, pc.schur_emax = schur[:3]     # (real intervals: BE heat control)
         self.pc = pc
 
     def mult(self, x):

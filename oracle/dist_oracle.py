@@ -134,7 +134,7 @@ class ShardedHeatSystem:
         def inner(At, dinv, spec, rhs):
             if spec.its == 0:
                 return dinv * rhs
-            return ko.chebyshev_jacobi(At, dinv, rhs, spec.emin, spec.emax, spec.its)
+            return ko.chebyshev_jacobi(At, dinv, rhs, spec.emin, spec.emax, spec.its, spec.eimag)
 
         def solve(blk, c, rhs):
             key = (id(blk), c)

@@ -228,12 +228,16 @@ def _gmres_driver(A, B, b, x, *, restart, rtol, atol, divtol, max_it, flexible,
     haptol = 1.0e-30
     its = 0
     m = restart
-    V = np.zeros((m + 1, n))
-    Z = np.zeros((m, n)) if flexible else None
-    H = np.zeros((m + 1, m))
-    cc = np.zeros(m)
-    ss = np.zeros(m)
-    grs = np.zeros(m + 1)
+    # (the arithmetic type follows the right-hand side: float64 everywhere in the parity tests;
+    # numpy.longdouble in the extended-precision study of the BE trajectories,
+    # tests/golden/make_extended_histories.py)
+    dt = b.dtype
+    V = np.zeros((m + 1, n), dtype=dt)
+    Z = np.zeros((m, n), dtype=dt) if flexible else None
+    H = np.zeros((m + 1, m), dtype=dt)
+    cc = np.zeros(m, dtype=dt)
+    ss = np.zeros(m, dtype=dt)
+    grs = np.zeros(m + 1, dtype=dt)
     reason = 0
     while True:
         # KSPInitialResidual
@@ -313,7 +317,7 @@ def _gmres_driver(A, B, b, x, *, restart, rtol, atol, divtol, max_it, flexible,
                 monitor(its, rn)
         # KSPGMRESBuildSoln
         if it > 0:
-            y = np.zeros(it)
+            y = np.zeros(it, dtype=dt)
             for k in range(it - 1, -1, -1):
                 y[k] = (grs[k] - H[k, k + 1:it] @ y[k + 1:]) / H[k, k]
             if flexible:
@@ -432,12 +436,44 @@ def minres(A, B, b, x, *, rtol, atol, divtol, max_it, monitor=None, restart=None
     return res
 
 
-def chebyshev_jacobi(A, dinv, b, emin, emax, its):
+def chebyshev_ellipse_coefficients(emin, emax, eimag, its):
+    """Coefficients ``(c1, c2, c3)`` of steps ``2 .. its`` of the Chebyshev iteration for a
+    spectrum inside the ellipse with centre ``d = (emax + emin) / 2`` and semi-axes
+    ``a = (emax - emin) / 2`` (real direction) and ``eimag`` (imaginary direction):
+    ``p_{k+1} = c1 p_{k-1} + c2 p_k + c3 D^-1 (b - A p_k)`` (Manteuffel, Numer. Math. 28, 1977:
+    ``alpha_1 = 2d / (2d^2 - c^2)``, ``alpha_n = 1 / (d - (c^2 / 4) alpha_{n-1})``,
+    ``beta_n = d alpha_n - 1`` with ``c^2 = a^2 - eimag^2``, which may be negative -- the
+    recurrence only ever sees ``c^2``, so the arithmetic stays real).  The first step is
+    ``p_1 = (1 / d) D^-1 b`` as for a real interval.  Not in the reference: its sub-solves on the
+    non-symmetric convection blocks are BoomerAMG cycles (``control.py:2277-2288``); the sweep
+    shape (one SpMV per step, three-term update) is the one north_star prescribes."""
+    d = 0.5 * (emax + emin)
+    a = 0.5 * (emax - emin)
+    c2 = a * a - eimag * eimag
+    out = []
+    alpha = 1.0 / d
+    for n in range(1, its):
+        alpha = 1.0 / (d - (0.5 if n == 1 else 0.25) * c2 * alpha)
+        beta = d * alpha - 1.0
+        out.append((-beta, 1.0 + beta, alpha))
+    return out
+
+
+def chebyshev_jacobi(A, dinv, b, emin, emax, its, eimag=0.0):
     """``KSPSolve_Chebyshev`` (first kind) with ``PCJACOBI``, zero guess, ``its`` steps.
 
     Options of the reference: ``control/control.py:1973-1982`` (``ksp_max_it 20``,
-    ``rtol = atol = 0``, fixed eigenvalue bounds, no estimation).
+    ``rtol = atol = 0``, fixed eigenvalue bounds, no estimation).  ``eimag > 0``: the same
+    three-term sweep with the coefficients of an ellipse (``chebyshev_ellipse_coefficients``),
+    for blocks with a convection term.
     """
+    if eimag > 0.0:
+        p_km1 = np.zeros_like(b)
+        p_k = (2.0 / (emax + emin)) * (dinv * b) + p_km1
+        for c1, c2, c3 in chebyshev_ellipse_coefficients(emin, emax, eimag, its):
+            z = dinv * (b - A @ p_k)
+            p_km1, p_k = p_k, c1 * p_km1 + c2 * p_k + c3 * z
+        return p_k
     scale = 2.0 / (emax + emin)
     alpha = 1.0 - scale * emin
     mu = 1.0 / alpha
@@ -478,8 +514,9 @@ class OracleSystem:
     def __init__(self, nx0, nx1, block_00, block_01, block_10, block_11, *,
                  n_blocks_00=1, n_blocks_11=1, sub_n_blocks_00_0=None,
                  sub_n_blocks_11_0=None, nullspace_0=None, nullspace_1=None,
-                 CN=False):
+                 CN=False, dtype=np.float64):
         n0, n1 = n_blocks_00, n_blocks_11
+        self.dtype = dtype      # float64; numpy.longdouble only in the extended-precision study
         if nullspace_0 is None:
             nullspace_0 = tuple(NoneNullspace() for _ in range(n0))
         if nullspace_1 is None:
@@ -507,7 +544,7 @@ class OracleSystem:
 
     # -- preconditioner.py:375-543
     def mult(self, x):
-        x0, x1 = self.split(np.asarray(x, dtype=np.float64))
+        x0, x1 = self.split(np.asarray(x, dtype=self.dtype))
         n0, n1 = self.n0, self.n1
         xc0 = x0.copy()
         xc1 = x1.copy()
@@ -550,7 +587,7 @@ class OracleSystem:
 
     # -- preconditioner.py:562-656
     def pc_apply(self, pc_fn, x):
-        b0, b1 = self.split(np.asarray(x, dtype=np.float64))
+        b0, b1 = self.split(np.asarray(x, dtype=self.dtype))
         n0, n1 = self.n0, self.n1
         b0c = b0.copy()
         b1c = b1.copy()
@@ -658,13 +695,14 @@ class ChebSpec:
     its: int
     emin: float
     emax: float
+    eimag: float = 0.0      # > 0: imaginary semi-axis of the spectrum's ellipse (convection blocks)
 
 
 def _inner_solve(At, spec, rhs):
     dinv = 1.0 / At.diagonal()
     if spec.its == 0:
         return dinv * rhs
-    return chebyshev_jacobi(At, dinv, rhs, spec.emin, spec.emax, spec.its)
+    return chebyshev_jacobi(At, dinv, rhs, spec.emin, spec.emax, spec.its, spec.eimag)
 
 
 def _bc(v, nodes):
@@ -708,7 +746,7 @@ def pc_instationary_BE(M, block_01, block_10, n_t, tau, beta, nodes, mass_spec,
         if schur_spec.its == 0:
             return dinv * rhs
         return chebyshev_jacobi(At, dinv, rhs, schur_spec.emin, schur_spec.emax,
-                                schur_spec.its)
+                                schur_spec.its, schur_spec.eimag)
 
     def pc_linear(u_0, u_1, b_0, b_1):
         # (1,1)-block, control.py:2193-2206
@@ -785,7 +823,7 @@ def pc_instationary_CN(M, block_01, block_10, n_t, tau, beta, nodes, mass_spec,
         if schur_spec.its == 0:
             return dinv * rhs
         return chebyshev_jacobi(At, dinv, rhs, schur_spec.emin, schur_spec.emax,
-                                schur_spec.its)
+                                schur_spec.its, schur_spec.eimag)
 
     def pc_linear(u_0, u_1, b_0, b_1):
         # (1,1)-block, control.py:1997-2014
