@@ -63,6 +63,21 @@ def roofline_check(roof):
     return True
 
 
+def pc_stages(gsys, lib, h, d_x, d_y):
+    """One application of a block-Schur preconditioner replayed step by step (kkt_time_pc_stages)."""
+    from control_amd import _lib
+    ps = _lib.PcStageTimes()
+    gsys._ck(lib.kkt_time_pc_stages(h, d_x, d_y, C.byref(ps)))     # warm-up
+    gsys._ck(lib.kkt_time_pc_stages(h, d_x, d_y, C.byref(ps)))
+    return {"time_sweeps": ps.sweeps_ms, "batched_steps": ps.batched_ms,
+            "rank_handoffs": ps.comm_ms, "sum": ps.total_ms,
+            "sweep_launches": int(ps.sweep_launches), "sweep_phases": int(ps.sweep_phases),
+            "batched_launches": int(ps.batched_launches), "handoff_steps": int(ps.comm_steps),
+            "note": "one application replayed step by step with an event after every step "
+                    "(no hipGraph: launch gaps are inside the figures); rank_handoffs includes "
+                    "the wait for the neighbour rank's stage of the sweep pipeline"}
+
+
 def stage_breakdown(gsys, lib, h, d_b, d_u, d_x, d_y, n_local, its, krylov_type, with_pc_stages=True):
     """SURVEY 8e itemisation: a short solve with HIP events between the stages of every
     iteration (outside the timed region), and one preconditioner application step by step."""
@@ -93,17 +108,7 @@ def stage_breakdown(gsys, lib, h, d_b, d_u, d_x, d_y, n_local, its, krylov_type,
         out["krylov_iteration_ms"] = {"error": f"{type(e).__name__}: {e}"}
     if with_pc_stages:
         try:
-            ps = _lib.PcStageTimes()
-            gsys._ck(lib.kkt_time_pc_stages(h, d_x, d_y, C.byref(ps)))     # warm-up
-            gsys._ck(lib.kkt_time_pc_stages(h, d_x, d_y, C.byref(ps)))
-            out["preconditioner_application_ms"] = {
-                "time_sweeps": ps.sweeps_ms, "batched_steps": ps.batched_ms,
-                "rank_handoffs": ps.comm_ms, "sum": ps.total_ms,
-                "sweep_launches": int(ps.sweep_launches), "sweep_phases": int(ps.sweep_phases),
-                "batched_launches": int(ps.batched_launches), "handoff_steps": int(ps.comm_steps),
-                "note": "one application replayed step by step with an event after every step "
-                        "(no hipGraph: launch gaps are inside the figures); rank_handoffs includes "
-                        "the wait for the neighbour rank's stage of the sweep pipeline"}
+            out["preconditioner_application_ms"] = pc_stages(gsys, lib, h, d_x, d_y)
         except Exception as e:      # noqa: BLE001
             out["preconditioner_application_ms"] = {"error": f"{type(e).__name__}: {e}"}
     return out
@@ -327,6 +332,23 @@ def bench_stokes(args, rank, world, local_rank):
     stages = stage_breakdown(outer, lib, h, d_x, d_u, d_x, d_y, n_local, min(args.steps, 10), 1,
                              with_pc_stages=False)
     inner_info = gpc.inner.info() if hasattr(gpc, "inner") else {}
+    # the nested velocity solve's block-Schur preconditioner, itemised (5 applications of it and
+    # 5 velocity-operator applies make up most of one StokesPC application)
+    try:
+        inner = gpc.inner
+        ih, n_in = inner.handle, inner.info()["n_local"]
+        dvi = []
+        for seed in (1, 2):
+            d = C.c_void_p()
+            inner._ck(lib.kkt_vec_alloc(ih, C.byref(d)))
+            inner._ck(lib.kkt_vec_upload(ih, d, _lib.f64(common.rng_vector(n_in, seed + rank))[1]))
+            dvi.append(d)
+        inner._ck(lib.kkt_time_apply(ih, dvi[0], dvi[1], 5, C.byref(ms)))
+        inner._ck(lib.kkt_time_apply(ih, dvi[0], dvi[1], 20, C.byref(ms)))
+        stages["velocity_preconditioner_application_ms"] = pc_stages(inner, lib, ih, dvi[0], dvi[1])
+        stages["velocity_operator_apply_ms"] = ms.value / 20
+    except Exception as e:      # noqa: BLE001 -- a side measurement must not lose the line
+        stages["velocity_preconditioner_application_ms"] = {"error": f"{type(e).__name__}: {e}"}
     if rank != 0:
         return None
     alg = info["bytes_streamed"]          # what the launch must move (index arrays once)

@@ -32,7 +32,9 @@ class PcDesc(C.Structure):
                 ("n_bc", C.c_int64), ("bc_idx", c_i32p),
                 ("mass_its", C.c_int), ("mass_emin", C.c_double), ("mass_emax", C.c_double),
                 ("schur_its", C.c_int), ("schur_emin", C.c_double),
-                ("schur_emax", C.c_double), ("schur_eimag", C.c_double)]
+                ("schur_emax", C.c_double), ("schur_eimag", C.c_double),
+                ("coarse_cycles", C.c_int), ("n_coarse", C.c_int64),
+                ("p_indptr", c_i32p), ("p_indices", c_i32p), ("p_values", c_f64p)]
 
 
 class PcStokesDesc(C.Structure):

@@ -32,6 +32,13 @@ __device__ __forceinline__ gcd_p resolve(const VRef &r, const Bases &B) {
     return (gcd_p)(p + r.off);
 }
 
+// Buffers that must be zero before a persistent launch (tags, flags) are cleared by a KERNEL,
+// not by hipMemsetAsync: inside a captured preconditioner application that is a kernel node
+// instead of a memset node (rocprofv3 of ROCm 7.2 crashed in hipGraphLaunch of the graphs that
+// held memset nodes next to the persistent kernels; a graph of kernel nodes only is the
+// conservative shape).
+void launch_zero_bytes(hipStream_t s, void *p, size_t nbytes);
+
 // ---------------------------------------------------------------- fused block-row SpMV
 //
 // Layout ("SELL-64R"): rows are cut into slices of C = 64*R consecutive rows; slice s
@@ -345,49 +352,10 @@ __device__ __forceinline__ void accumulate_generic(const RowOp &op, const TermFn
             }
         }
     } else {
-#ifndef KKT_GENERIC_SERIAL
-        // Slices without a compile-time width (row-sorted P2 blocks: 9 or 19 entries, the
-        // rectangular divergence blocks): chunks of KC slots whose loads are all in flight
-        // together -- indices of a chunk, then its values and gathers, then the fma chain in slot
-        // order (the row's CSR order) -- with the next chunk's indices requested under the
-        // current chunk's gathers.  The slice width is wave-uniform, so the guards are scalar
-        // branches; slots past the width are not loaded at all.  (The serial loop below kept one
-        // index -> gather dependency in flight per slot: 3.5 TB/s on the Stokes operator.)
-        constexpr int KC = 10;
-        for (int t = 0; t < (w > 0 ? nterms : 0); ++t) {
-            const SpmvTerm tm = terms(t);
-            const gcd_p vp = (gcd_p)tm.vals + base;
-            const gcd_p x = resolve(tm.x, bases);
-            int c[KC][R];
-#pragma unroll
-            for (int k = 0; k < KC; ++k)
-                if (k < w) load_cols<R>(colp + (size_t)k * C, c[k]);
-            for (int k0 = 0; k0 < w; k0 += KC) {
-                double v[KC][R], xv[KC][R];
-                const int n = w - k0;       // live slots of this chunk (>= 1), wave-uniform
-#pragma unroll
-                for (int k = 0; k < KC; ++k)
-                    if (k < n) load_vals<R, NT>(vp + (size_t)(k0 + k) * C, v[k]);
-#pragma unroll
-                for (int k = 0; k < KC; ++k)
-                    if (k < n) {
-#pragma unroll
-                        for (int q = 0; q < R; ++q) xv[k][q] = ldv<COH>(x + c[k][q]);
-                    }
-                const int n1 = n - KC;      // live slots of the next chunk
-#pragma unroll
-                for (int k = 0; k < KC; ++k)
-                    if (k < n1) load_cols<R>(colp + (size_t)(k0 + KC + k) * C, c[k]);
-#pragma unroll
-                for (int k = 0; k < KC; ++k)
-                    if (k < n) {
-#pragma unroll
-                        for (int q = 0; q < R; ++q)
-                            acc[q] = __builtin_fma(v[k][q], xv[k][q], acc[q]);
-                    }
-            }
-        }
-#else
+        // (measured on the Stokes operator, same box: chunks of 10 slots with all loads of a chunk
+        // in flight and padded tails ran exactly as fast as this loop, 0.886 against 0.889 ms, and
+        // chunks guarded by scalar branches slower, 1.11 ms -- the waves of this kernel are not
+        // short of memory-level parallelism)
         for (int t = 0; t < nterms; ++t) {
             const SpmvTerm tm = terms(t);
             const gcd_p vp = (gcd_p)tm.vals + base;
@@ -403,7 +371,6 @@ __device__ __forceinline__ void accumulate_generic(const RowOp &op, const TermFn
                     acc[q] = __builtin_fma(v[q], ldv<COH>(x + c[q]), acc[q]);
             }
         }
-#endif
     }
 }
 
@@ -1282,8 +1249,8 @@ void launch_row_program_g(hipStream_t s, const RowOp *d_ops, const PhaseLite *d_
                           unsigned long long *g1, size_t granule_words, unsigned *d_err) {
     if (nphases <= 0 || nwg <= 0) return;
     // tags of an earlier launch must not match this launch's epochs
-    (void)hipMemsetAsync(g0, 0, granule_words * sizeof(unsigned long long), s);
-    (void)hipMemsetAsync(g1, 0, granule_words * sizeof(unsigned long long), s);
+    launch_zero_bytes(s, g0, granule_words * sizeof(unsigned long long));
+    launch_zero_bytes(s, g1, granule_words * sizeof(unsigned long long));
     hipLaunchKernelGGL(pick_program_g(uniform_w), dim3(nwg), dim3(64 * waves_per_wg), 0, s, d_ops,
                        d_lite, nphases, g0, g1,
                        (unsigned)(granule_words * sizeof(unsigned long long)), d_err);
@@ -1303,8 +1270,8 @@ void launch_row_program_gw(hipStream_t s, const RowOp *d_ops, int nphases, int n
                            int waves_per_wg, unsigned long long *g0, unsigned long long *g1,
                            size_t granule_words, unsigned *d_err) {
     if (nphases <= 0 || nwg <= 0) return;
-    (void)hipMemsetAsync(g0, 0, granule_words * sizeof(unsigned long long), s);
-    (void)hipMemsetAsync(g1, 0, granule_words * sizeof(unsigned long long), s);
+    launch_zero_bytes(s, g0, granule_words * sizeof(unsigned long long));
+    launch_zero_bytes(s, g1, granule_words * sizeof(unsigned long long));
     hipLaunchKernelGGL(pc_row_program_gw<2>, dim3(nwg), dim3(64 * waves_per_wg), 0, s, d_ops,
                        nphases, g0, g1, d_err);
 }
@@ -1349,7 +1316,7 @@ void launch_row_program(hipStream_t s, const RowOp *d_ops, int nphases, int nwg,
                         int R, int uniform_w, const int32_t *d_dep, unsigned *d_flags,
                         unsigned *d_err, bool lowreg) {
     if (nphases <= 0 || nwg <= 0) return;
-    (void)hipMemsetAsync(d_flags, 0, (size_t)prog_flag_words(nwg) * sizeof(unsigned), s);
+    launch_zero_bytes(s, d_flags, (size_t)prog_flag_words(nwg) * sizeof(unsigned));
     const dim3 grid(nwg), block(64 * waves_per_wg);
     hipLaunchKernelGGL(pick_program(R, uniform_w, lowreg), grid, block, 0, s, d_ops, nphases,
                        reinterpret_cast<const int2 *>(d_dep), d_flags, d_err);
@@ -1846,6 +1813,19 @@ __global__ void fill_kernel(double *__restrict__ y, double v, int64_t n) {
          p += (int64_t)gridDim.x * blockDim.x)
         y[p] = v;
 }
+// (sizes are multiples of 4 bytes: flag words and 8-byte granule halves)
+__global__ void zero_words_kernel(unsigned *__restrict__ p, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x)
+        p[i] = 0u;
+}
+void launch_zero_bytes(hipStream_t s, void *p, size_t nbytes) {
+    const size_t n = nbytes / 4;
+    if (n == 0) return;
+    hipLaunchKernelGGL(zero_words_kernel, dim3(grid_for((int64_t)n)), dim3(256), 0, s,
+                       (unsigned *)p, n);
+}
+
 void launch_fill(hipStream_t s, double *y, double v, int64_t n) {
     if (n <= 0) return;
     hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, v, n);

@@ -210,6 +210,7 @@ void launch_mdot(hipStream_t s, const double *w, VecList V, int nv, int64_t n,
                  double *scratch, double *out);
 // out[0] = sqrt(<w, w> + extra) where extra = (add ? *add : 0)
 void launch_norm2_finish(hipStream_t s, const double *dot, double *out);
+void launch_zero_bytes(hipStream_t s, void *p, size_t nbytes);   // kernel node, not a memset node
 void launch_flag_to_double(hipStream_t s, const unsigned *flag, double *out);
 // w += sign * sum_i coef[i] * V_i   (coef in device memory)
 void launch_maxpy(hipStream_t s, double *w, VecList V, const double *coef, double sign,

@@ -690,6 +690,10 @@ bool SchurPC::timed_out(std::string *why) {
                std::to_string(rec[12]) + "/" + std::to_string(rec[13]) + " old " +
                std::to_string(rec[14]) + "/" + std::to_string(rec[15]) +
                (rec[16] ? ", both iterates)" : ", newest iterate only)");
+    if (e & 8u)
+        msg = "persistent sweep kernel abandoned at entry: its workgroups are not co-resident (" +
+              std::to_string(rec[17]) + " of " + std::to_string(rec[18]) +
+              " tiles checked in within the bounded wait; tile form)";
     if (e & 2u)
         msg += " (data-flow form: workgroup " + std::to_string(rec[24]) + " wave " +
                std::to_string(rec[25]) + " lane " + std::to_string(rec[26]) + ", phase " +

@@ -258,7 +258,10 @@ int System::find_or_add_pattern(int64_t nrows, int64_t ncols, const int32_t *ind
     const char *sort_env = opt("sell_sort");   // read per pattern: tests toggle it
     const bool allow_sort = !(sort_env && sort_env[0] == '0');
     if (allow_sort && nnz > 0) {
-        const int64_t npos = (int64_t)P.nslices * C, sigma = 8 * (int64_t)C;
+        // (window: 8 slices = the rows of two workgroups, unless "sell_sigma" says otherwise)
+        const char *sg = opt("sell_sigma");
+        const int sig_slices = sg ? std::max(1, std::min(64, std::atoi(sg))) : 8;
+        const int64_t npos = (int64_t)P.nslices * C, sigma = sig_slices * (int64_t)C;
         std::vector<int32_t> cand(npos, -1);
         for (int64_t w0 = 0; w0 < nrows; w0 += sigma) {
             const int64_t w1 = std::min<int64_t>(nrows, w0 + sigma);

@@ -108,6 +108,51 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
         X[nkp - 1] = 0.0;
         X[2 * (size_t)nkp - 1] = 0.0;
     }
+    // ---- residency check.  The hand-offs below assume that every tile of the grid is running at
+    // the same time (one workgroup per CU).  If the device cannot place them all at once -- CUs
+    // masked off, another process holding wave slots -- the resident tiles would each spin 2^21
+    // times in their first hand-off before giving up.  Instead every tile checks in on a counter
+    // (it only ever grows: each launch adds exactly gridDim.x, so the value a tile must see is the
+    // next multiple above what its own atomic returned) and waits a bounded ~50 us for the others;
+    // a tile that does not see them all marks the launch as abandoned, and every tile -- those
+    // still waiting and those scheduled later -- leaves at once.  The host then falls back to
+    // plain launches (kkt_info.program_fallbacks).
+    __shared__ int s_bail;
+    if (tid == 0) {
+        typedef KKT_GLOBAL unsigned long long *gu64a_p;
+        const gu64a_p ctr = (gu64a_p)(A.err + 2), bail = (gu64a_p)(A.err + 4);
+        const unsigned long long nt_ = gridDim.x;
+        const bool skip = A.debug_drop < 0 && tile == 0;      // test hook: tile 0 never checks in
+        unsigned long long old = 0ull;
+        if (!skip) old = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else old = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long target = (old / nt_ + 1ull) * nt_;
+        int bad = 0;
+        unsigned long long seen = old;
+        for (int spin = 0; spin < 256; ++spin) {
+            seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (seen >= target) break;
+            if (__hip_atomic_load(bail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == target) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (seen < target) {
+            __hip_atomic_store(bail, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bad = 1;
+        } else if (__hip_atomic_load(bail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == target) {
+            bad = 1;
+        }
+        if (bad) {
+            atomicOr(A.err, 8u);
+            if (atomicCAS(A.err + 1, 0u, 1u) == 0u) {
+                A.err[17] = (unsigned)(seen - (target - nt_));     // tiles that had checked in
+                A.err[18] = (unsigned)nt_;
+            }
+        }
+        s_bail = bad;
+    }
+    __syncthreads();
+    if (s_bail) return;
+
     const gci_p grow = (gci_p)grow_all + (size_t)tile * nkp;
     const gcb_p rowmask = (gcb_p)rowmask_;
 
@@ -876,11 +921,14 @@ void launch_tile_sweep(hipStream_t s, const TileArgs &a, const TileLevel *d_leve
             throw TileLaunchError{std::string("tile sweep program: ") + what + ": " +
                                   hipGetErrorString(e)};
     };
-    if (a.clear)
+    (void)hipGetLastError();
+    if (a.clear) {
         for (int i = 0; i < 2; ++i) {
-            chk(hipMemsetAsync(a.gnew[i], 0, granule_words * sizeof(unsigned long long), s), "clearing the granule buffers");
-            chk(hipMemsetAsync(a.gold[i], 0, granule_words * sizeof(unsigned long long), s), "clearing the granule buffers");
+            launch_zero_bytes(s, a.gnew[i], granule_words * sizeof(unsigned long long));
+            launch_zero_bytes(s, a.gold[i], granule_words * sizeof(unsigned long long));
         }
+        chk(hipGetLastError(), "clearing the granule buffers");
+    }
     const size_t lds = tile_sweep_lds_bytes(a.nk_pad, a.its);
     tile_fn f = pick_tile(a.W, a.rpt, threads, a.fused_update != 0, a.hslots);
     if (!f) throw TileLaunchError{"tile sweep program: no kernel variant for this plan"};

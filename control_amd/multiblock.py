@@ -78,6 +78,16 @@ class ChebSpec:
     emin: float = 0.0
     emax: float = 0.0
     eimag: float = 0.0
+    coarse: object = None         # CoarseSpace: two-grid cycles (its = smoothing sweeps per cycle)
+
+
+@dataclass
+class CoarseSpace:
+    """Coarse space of the two-grid form of the Schur sub-solves (``kkt_pc_desc.coarse_*``):
+    ``P`` (n x n_c, scipy sparse / CSR triple; ``control_amd.coarse.multilinear_coarse_space``)
+    and the number of cycles [Galerkin correction, ``its`` smoothing sweeps]."""
+    P: object
+    cycles: int = 1
 
 
 @dataclass
@@ -190,7 +200,7 @@ def _array_of(v, n, nx):
 _ENV_OPTION_KEYS = ("sell_r", "sell_sort", "no_graph", "persistent", "prog_mode", "prog_waves",
                     "prog_steps", "tile_depth", "tile_waves", "lanes", "lane_chunks",
                     "kernarg_ops", "shared_rows", "verbose", "stamps", "tile_poll_delay",
-                    "tile_unfused", "stage_timers")
+                    "tile_unfused", "stage_timers", "sell_sigma")
 
 
 # ------------------------------------------------------------------ the block system

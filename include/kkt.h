@@ -192,6 +192,19 @@ typedef struct kkt_pc_desc {
                             ellipse (Manteuffel 1977).  0: real interval.  With schur_emin <= 0 it
                             is estimated per matrix too (symmetric part for the interval, spectral
                             radius of the skew part for the semi-axis). */
+    /* Two-grid form of the Schur sub-solves (coarse_cycles == 0: off).  A sub-solve is
+     * `coarse_cycles` times [x += P (P^T A P)^-1 P^T (b - A x); `schur_its` Jacobi-Chebyshev
+     * sweeps on [schur_emin, schur_emax] from x] -- the reference calls BoomerAMG here
+     * (control.py:2277-2288); the sweeps keep the shape north_star prescribes and only have to
+     * cover the part of the spectrum the coarse space does not see (8 sweeps on [emax / 30, emax]
+     * instead of 80 on the whole spectrum of 256^2 P1).  P: nx x n_coarse CSR, rows of Dirichlet
+     * dofs empty (control_amd.coarse.multilinear_coarse_space builds it from dof coordinates).
+     * The Galerkin matrices are formed and inverted at set-up, one per distinct sub-solve matrix.
+     * With schur_emin <= 0: emax from the matrix, emin = emax / 30; schur_its = -1: 8. */
+    int coarse_cycles;
+    int64_t n_coarse;
+    const int32_t *p_indptr, *p_indices;
+    const double *p_values;
 } kkt_pc_desc;
 
 int kkt_set_pc_schur(kkt_handle h, const kkt_pc_desc *desc);

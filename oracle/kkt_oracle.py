@@ -495,6 +495,63 @@ def chebyshev_jacobi(A, dinv, b, emin, emax, its, eimag=0.0):
     return p_k
 
 
+def chebyshev_jacobi_from(A, dinv, b, x0, emin, emax, its, eimag=0.0):
+    """``its`` steps of the same iteration from the initial guess ``x0`` (``KSPSolve_Chebyshev``
+    with a non-zero guess: ``p_1 = x_0 + scale B (b - A x_0)``, then the three-term recurrence
+    with ``p_0 = x_0`` and the coefficients of the zero-guess sequence): ``its`` SpMVs."""
+    if its <= 0:
+        return x0.copy()
+    scale = 2.0 / (emax + emin)
+    p_km1 = x0
+    p_k = x0 + scale * (dinv * (b - A @ x0))
+    if eimag > 0.0:
+        coefs = chebyshev_ellipse_coefficients(emin, emax, eimag, its)
+    else:
+        alpha = 1.0 - scale * emin
+        mu = 1.0 / alpha
+        omegaprod = 2.0 / alpha
+        c_km1, c_k = 1.0, mu
+        coefs = []
+        for _ in range(1, its):
+            c_kp1 = 2.0 * mu * c_k - c_km1
+            omega = omegaprod * c_k / c_kp1
+            coefs.append((1.0 - omega, omega, scale * omega))
+            c_km1, c_k = c_k, c_kp1
+    for c1, c2, c3 in coefs:
+        z = dinv * (b - A @ p_k)
+        p_km1, p_k = p_k, c1 * p_km1 + c2 * p_k + c3 * z
+    return p_k
+
+
+@dataclass
+class CoarseSpace:
+    """Coarse space of the two-grid form of the sub-solves: ``P`` (n x n_c, scipy sparse; rows of
+    Dirichlet dofs empty) and the number of cycles.  Not in the reference, which calls BoomerAMG
+    for these solves (``control.py:2277-2288``): a cycle is the Galerkin coarse correction
+    ``x += P (P^T A P)^-1 P^T (b - A x)`` followed by ``its`` Jacobi-Chebyshev smoothing sweeps
+    on ``[emin, emax]`` (the upper part of the spectrum: what the coarse space does not see)."""
+    P: object
+    cycles: int = 1
+
+
+def coarse_chebyshev(A, dinv, b, spec, Einv):
+    """Sub-solve with coarse corrections: ``cycles`` x [Galerkin correction, ``its`` smoothing
+    sweeps from the corrected iterate].  The first correction acts on ``b`` (zero guess)."""
+    P = spec.coarse.P
+    x = np.zeros_like(b)
+    for c in range(spec.coarse.cycles):
+        r = b if c == 0 else b - A @ x
+        x = x + P @ (Einv @ (P.T @ r))
+        x = chebyshev_jacobi_from(A, dinv, b, x, spec.emin, spec.emax, spec.its, spec.eimag)
+    return x
+
+
+def coarse_inverse(At, coarse):
+    """``(P^T A P)^-1`` of the bc-assembled sub-solve matrix (dense)."""
+    P = coarse.P
+    return np.linalg.inv((P.T @ (At @ P)).toarray())
+
+
 # ----------------------------------------------------------------------- the system
 
 
@@ -696,10 +753,14 @@ class ChebSpec:
     emin: float
     emax: float
     eimag: float = 0.0      # > 0: imaginary semi-axis of the spectrum's ellipse (convection blocks)
+    coarse: object = None   # CoarseSpace: two-grid cycles (its = smoothing sweeps per cycle)
 
 
-def _inner_solve(At, spec, rhs):
+def _inner_solve(At, spec, rhs, Einv=None):
     dinv = 1.0 / At.diagonal()
+    if getattr(spec, "coarse", None) is not None:
+        return coarse_chebyshev(At, dinv, rhs, spec, coarse_inverse(At, spec.coarse)
+                                if Einv is None else Einv)
     if spec.its == 0:
         return dinv * rhs
     return chebyshev_jacobi(At, dinv, rhs, spec.emin, spec.emax, spec.its, spec.eimag)
@@ -716,14 +777,18 @@ def pc_stationary(M, D_v, D_zeta, beta, nodes, mass_spec, schur_spec):
     S1 = assemble_with_bcs(D_v + (1.0 / beta**0.5) * M, nodes)
     S2 = assemble_with_bcs(D_zeta + (1.0 / beta**0.5) * M, nodes)
 
+    co = getattr(schur_spec, "coarse", None)
+    E1 = coarse_inverse(S1, co) if co is not None else None
+    E2 = coarse_inverse(S2, co) if co is not None else None
+
     def pc_linear(u_0, u_1, b_0, b_1):
         u_0[0] = _inner_solve(Mt, mass_spec, b_0[0])
         b = D_v @ u_0[0] - b_1[0]
         _bc(b, nodes)
-        u_1[0] = _inner_solve(S1, schur_spec, b)
+        u_1[0] = _inner_solve(S1, schur_spec, b, E1)
         b = M @ u_1[0]
         _bc(b, nodes)
-        u_1[0] = _inner_solve(S2, schur_spec, b)
+        u_1[0] = _inner_solve(S2, schur_spec, b, E2)
     return pc_linear
 
 
@@ -741,8 +806,11 @@ def pc_instationary_BE(M, block_01, block_10, n_t, tau, beta, nodes, mass_spec,
         key = (id(blk), c)
         if key not in cache:
             At = assemble_with_bcs(blk if c == 0.0 else blk + c * M, nodes)
-            cache[key] = (At, 1.0 / At.diagonal(), blk)
-        At, dinv, _ = cache[key]
+            Einv = coarse_inverse(At, schur_spec.coarse) if schur_spec.coarse is not None else None
+            cache[key] = (At, 1.0 / At.diagonal(), blk, Einv)
+        At, dinv, _, Einv = cache[key]
+        if schur_spec.coarse is not None:
+            return coarse_chebyshev(At, dinv, rhs, schur_spec, Einv)
         if schur_spec.its == 0:
             return dinv * rhs
         return chebyshev_jacobi(At, dinv, rhs, schur_spec.emin, schur_spec.emax,
@@ -818,8 +886,11 @@ def pc_instationary_CN(M, block_01, block_10, n_t, tau, beta, nodes, mass_spec,
         key = (id(blk), c)
         if key not in cache:
             At = assemble_with_bcs(blk if c == 0.0 else blk + c * M, nodes)
-            cache[key] = (At, 1.0 / At.diagonal(), blk)
-        At, dinv, _ = cache[key]
+            Einv = coarse_inverse(At, schur_spec.coarse) if schur_spec.coarse is not None else None
+            cache[key] = (At, 1.0 / At.diagonal(), blk, Einv)
+        At, dinv, _, Einv = cache[key]
+        if schur_spec.coarse is not None:
+            return coarse_chebyshev(At, dinv, rhs, schur_spec, Einv)
         if schur_spec.its == 0:
             return dinv * rhs
         return chebyshev_jacobi(At, dinv, rhs, schur_spec.emin, schur_spec.emax,

@@ -16,6 +16,9 @@ ap.add_argument("--nu", type=float, default=None)
 ap.add_argument("--schur", default="auto")
 ap.add_argument("--cn", action="store_true")
 ap.add_argument("--max-it", type=int, default=100)
+ap.add_argument("--rtol", type=float, default=1e-8)
+ap.add_argument("--atol", type=float, default=0.0)
+ap.add_argument("--nl-tol", type=float, default=1e-5)
 a = ap.parse_args()
 if a.case == "cavity":
     pb, v0, _ = common.navier_stokes_cavity_problem(n=a.n, n_t=a.n_t, CN=a.cn)
@@ -27,12 +30,15 @@ else:
 schur = (-1, 0.0, 0.0) if a.schur == "auto" else eval(a.schur)
 kp = (-1, 0.0, 0.0) if a.schur == "auto" else (schur[0], 0.02, 2.1)
 s = common.STOKES_SPECS
-sp = dict(common.NS_SOLVER_PARAMETERS, maximum_iterations=a.max_it)
+sp = dict(common.NS_SOLVER_PARAMETERS, maximum_iterations=a.max_it, relative_tolerance=a.rtol,
+          absolute_tolerance=a.atol)
 gls = picard.GpuLinearSolver(pb, mass=(20, 0.3924, 2.0598), schur=schur, kp=kp, mp=(20, 0.5, 2.0),
                              solver_parameters=sp, options={"verbose": "1"})
 t = time.time()
 try:
     out = picard.incompressible_non_linear_solve(pb, gls, v=v0, max_non_linear_iter=10,
+                                                 relative_non_linear_tol=a.nl_tol,
+                                                 absolute_non_linear_tol=min(a.nl_tol, 1e-6),
                                                  print_error_non_linear=False)
     print(f"{a.case} n={a.n} nu={pb.nu} {'CN' if a.cn else 'BE'} schur={schur}: converged "
           f"{out['converged']} norms {['%.2e' % x for x in out['norms']]} linear its "

@@ -27,6 +27,21 @@ interior = np.ones(nx, bool)
 interior[nodes] = False
 
 
+def mkP(T):
+    """bilinear interpolation from the (T + 1)^2 grid of tile corners (boundary corners dropped)"""
+    rows, cols, vals = [], [], []
+    for r in np.flatnonzero(interior):
+        x, y = X[r, 0] * T, X[r, 1] * T
+        i, j = min(int(x), T - 1), min(int(y), T - 1)
+        fx, fy = x - i, y - j
+        for di, wx in ((0, 1 - fx), (1, fx)):
+            for dj, wy in ((0, 1 - fy), (1, fy)):
+                ci, cj = i + di, j + dj
+                if 0 < ci < T and 0 < cj < T and wx * wy > 0:
+                    rows.append(r); cols.append((ci - 1) * (T - 1) + (cj - 1)); vals.append(wx * wy)
+    return sp.csr_matrix((vals, (rows, cols)), shape=(nx, (T - 1) ** 2))
+
+
 def mkZ(T):
     tid = np.minimum((X[:, 0] * T).astype(int), T - 1) * T + np.minimum((X[:, 1] * T).astype(int), T - 1)
     rows = np.flatnonzero(interior)
@@ -53,7 +68,8 @@ lmin = spl.eigsh((Dh @ At @ Dh).tocsr(), k=1, sigma=0, which="LM", return_eigenv
 deg = int(np.ceil(1.6 * (2.0 / lmin) ** 0.5))
 print(f"n {n} tau {tau:.4f} lmin {lmin:.3e} degree {deg}")
 print(f"cheb{deg}", err(lambda b: ko.chebyshev_jacobi(At, dinv, b, 0.85 * lmin, 2.1, deg)))
-Z = mkZ(T)
+Z = mkP(T) if os.environ.get("PROTO_COARSE", "bilinear") == "bilinear" else mkZ(T)
+print("coarse space", Z.shape[1], "functions")
 E = (Z.T @ At @ Z).toarray()
 Ei = np.linalg.inv(E)
 

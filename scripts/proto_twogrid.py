@@ -47,6 +47,24 @@ for k in range(a.dim):
 ntile = a.tiles ** a.dim
 rows = np.flatnonzero(interior)
 Z = sp.csr_matrix((np.ones(rows.size), (rows, tid[rows])), shape=(nx, ntile))
+if os.environ.get("PROTO_COARSE", "bilinear") == "bilinear":
+    # multilinear interpolation from the grid of tile corners (boundary corners dropped)
+    T = a.tiles
+    rr, cc, vv = [], [], []
+    import itertools
+    for r in rows:
+        xs_ = X[r] * T
+        i0 = np.minimum(xs_.astype(int), T - 1)
+        f = xs_ - i0
+        for corner in itertools.product((0, 1), repeat=a.dim):
+            ci = i0 + np.array(corner)
+            wgt = np.prod([f[k] if corner[k] else 1 - f[k] for k in range(a.dim)])
+            if np.all(ci > 0) and np.all(ci < T) and wgt > 0:
+                idx = 0
+                for k in range(a.dim):
+                    idx = idx * (T - 1) + (ci[k] - 1)
+                rr.append(r); cc.append(idx); vv.append(wgt)
+    Z = sp.csr_matrix((vv, (rr, cc)), shape=(nx, (T - 1) ** a.dim))
 print(f"nx {nx}, tiles {ntile}, rows per tile ~{rows.size / ntile:.0f}, tau {tau:.4f}")
 
 

@@ -289,6 +289,34 @@ def test_sweep_program_timeout_falls_back_to_plain_launches():
     assert g2.info()["program_fallbacks"] == 1
 
 
+def test_tiles_that_are_not_co_resident_are_detected_at_kernel_entry():
+    """The tile programs need every workgroup of their grid running at once.  Each tile checks in
+    on a counter when the kernel starts and waits a bounded ~0.3 ms for the others; if they do not
+    all arrive (test hook: tile 0 never checks in -- what a masked-off CU or a busy device looks
+    like to the others) every tile leaves at once, the host says so on stderr, rebuilds the
+    preconditioner as plain launches and redoes the application: same result, one fall-back, in
+    well under the seconds a spin time-out deep inside a sweep used to take."""
+    import time
+    p = common.heat_problem(n=96, n_t=6)
+    schur = (6, 0.05, 2.1)
+    x = common.rng_vector(2 * p["m"] * p["sd"].n_dofs)
+    ref = common.gpu_system(p, options={"persistent": "0"}).pc_apply(
+        x, common.gpu_pc(p, (20, 0.5, 2.0), schur))
+    g = common.gpu_system(p, options={"persistent": "1", "prog_mode": "tile", "debug_drop_handoff": "-1"})
+    pc = common.gpu_pc(p, (20, 0.5, 2.0), schur)
+    g._set_pc(pc)
+    assert g.info()["sweep_form"] == 3
+    t0 = time.time()
+    got = g.pc_apply(x, pc)
+    dt = time.time() - t0
+    assert np.array_equal(got, ref)
+    inf = g.info()
+    assert inf["program_fallbacks"] == 1 and inf["sweep_form"] == 0
+    msg = g._lib.kkt_last_error(g.handle).decode()
+    assert "not co-resident" in msg and "plain launches" in msg, msg
+    assert dt < 1.0, dt
+
+
 def test_zero_right_hand_side_with_nonzero_guess_converges_to_zero():
     """KSPConvergedDefault's special case: with b = 0 the norm of the first residual takes the
     place of the (zero) right-hand-side norm, so a non-zero initial guess is iterated towards

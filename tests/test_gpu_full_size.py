@@ -224,14 +224,15 @@ def test_config4_heat3d_full_size():
 # ------------------------------------------------------------------ configs[4]
 def test_config5_navier_stokes_linearised_solve():
     """P2-P1 128 x 128, n_t = 64 (19.0 M unknowns): the system of one Picard linearisation about
-    a non-zero velocity (every time level its own convection block, mode G by nature).  Operator
+    a non-zero velocity at the reference's viscosity nu = 1/100 (test/test_control.py:4196; every
+    time level its own convection block, mode G by nature).  Operator
     against the oracle; then one FGMRES solve with the StokesPC whose true residual is evaluated
     with the ORACLE operator."""
     from control_amd import picard
     from control_amd.blocks import instationary_incompressible_blocks
     from oracle import kkt_oracle as ko
     t0 = time.time()
-    pb = common.navier_stokes_problem(n=128, n_t=64, nu=0.05, beta=1.0e-2)
+    pb = common.navier_stokes_problem(n=128, n_t=64, nu=1.0 / 100.0, beta=1.0e-2)   # tst.py:4196
     th, n_t = pb.disc, pb.n_t
     v = 0.5 * pb.v_d
     D = [pb.D_v(v[i]) for i in range(n_t)]
@@ -245,8 +246,10 @@ def test_config5_navier_stokes_linearised_solve():
         nullspace_0=tuple(ko.DirichletBCNullspace(th.boundary_v) for _ in range(2 * m)),
         nullspace_1=tuple(ko.ConstantNullspace() for _ in range(2 * m)))
     sp_ = dict(common.NS_SOLVER_PARAMETERS, relative_tolerance=1.0e-6, maximum_iterations=200)
-    gls = picard.GpuLinearSolver(pb, mass=(20, 0.3924, 2.0598), schur=(40, 0.002, 2.25),
-                                 kp=(40, 0.002, 2.1), mp=(20, 0.5, 2.0), solver_parameters=sp_)
+    # sub-solves: Chebyshev sweeps on the ellipse the library estimates for every level's matrix
+    # (the blocks carry a convection term: symmetric part -> interval, skew part -> semi-axis)
+    gls = picard.GpuLinearSolver(pb, mass=(20, 0.3924, 2.0598), schur=(-1, 0.0, 0.0),
+                                 kp=(-1, 0.0, 0.0), mp=(20, 0.5, 2.0), solver_parameters=sp_)
     rng = np.random.default_rng(common.SEED)
     x0 = rng.standard_normal((2 * m, th.n_v))
     x0[:, th.boundary_v] = 0.0

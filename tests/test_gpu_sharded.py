@@ -162,7 +162,12 @@ def test_bench_two_ranks_on_one_gpu_falls_back_to_gloo():
     assert it["preconditioner"] > it["operator"] > 0 and it["allreduce"] > 0, it
     pcs = st["preconditioner_application_ms"]
     assert pcs["time_sweeps"] > 0 and pcs["handoff_steps"] > 0 and pcs["rank_handoffs"] > 0, pcs
-    assert line["config"]["sweeps"]["program_fallbacks"] == 0
+    # (two ranks on ONE GPU: their 256-workgroup sweep kernels can end up half resident each; the
+    # residency check at kernel entry then abandons one launch and that rank -- and with it, by
+    # agreement, every rank -- continues with plain launches.  On distinct GPUs this cannot happen;
+    # here it may, and then the line must say so)
+    falls = line["config"]["sweeps"]["program_fallbacks"]
+    assert falls in (0, 1) and (falls == 0 or "warning" in line["config"]), line["config"]
 
 
 def test_bench_self_launch_two_ranks_with_the_sharded_config4_and_stokes_legs():
