@@ -168,9 +168,17 @@ def build_problem(args):
     if getattr(args, "schur_auto", False):
         # degree and one interval per sub-solve matrix from Lanczos estimates on the device
         schur = (-1, 0.0, 0.0)
+    coarse = None
+    if getattr(args, "coarse_cycles", 0) > 0:
+        # two-grid form of the sub-solves: Galerkin correction on the multilinear coarse space of
+        # ~coarse_nodes functions, then `schur_its` smoothing sweeps on the upper part of the
+        # spectrum (the reference runs BoomerAMG here)
+        from control_amd.coarse import multilinear_coarse_space
+        coarse = (multilinear_coarse_space(sd.coords, sd.boundary, target_nodes=args.coarse_nodes),
+                  args.coarse_cycles)
     return dict(sd=sd, tau=tau, beta=args.beta, n_t=args.n_t, CN=CN, m=blocks[4],
                 blocks=blocks[:4], nodes=sd.boundary, mass=(20,) + mass_bounds, schur=schur,
-                share_values=(args.mode == "S"))
+                coarse=coarse, share_values=(args.mode == "S"))
 
 
 def readme_rhs(p):
@@ -469,6 +477,10 @@ def main():
     ap.add_argument("--schur-auto", action="store_true",
                     help="degree and per-matrix intervals of the sub-solves from spectrum "
                          "estimates on the device (kkt_pc_desc.schur_its = -1) instead of the flags")
+    ap.add_argument("--coarse-cycles", type=int, default=0,
+                    help="two-grid form of the Schur sub-solves: cycles of [coarse correction, "
+                         "--schur-its sweeps on [--schur-emin, --schur-emax]] (0: plain Chebyshev)")
+    ap.add_argument("--coarse-nodes", type=int, default=300)
     ap.add_argument("--spmv-reps", type=int, default=50)
     ap.add_argument("--cpu-its", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -555,7 +567,7 @@ def measure_heat(args, rank, world, local_rank, tts):
     gsys = common.gpu_system(p, device=device, comm=comm, share_values=p["share_values"],
                              tile_coordinates=not args.no_tile_coordinates)
     lib, h = gsys._lib, gsys.handle
-    gpc = common.gpu_pc(p, p["mass"], p["schur"])
+    gpc = common.gpu_pc(p, p["mass"], p["schur"], coarse=p.get("coarse"))
     gsys._set_pc(gpc)
     gsys._ck(lib.kkt_sync(h))
     t_setup = time.perf_counter() - t_setup     # CSR -> device storage + preconditioner build
@@ -694,7 +706,10 @@ def measure_heat(args, rank, world, local_rank, tts):
             "unknowns": int(2 * p["m"] * p["sd"].n_dofs),
             "krylov": "gmres, left preconditioning, restart 10, classical Gram-Schmidt",
             "preconditioner": (f"block Schur: mass Chebyshev {p['mass']}, "
-                               f"Schur Chebyshev {p['schur']} (its, emin, emax)"),
+                               + (f"Schur sub-solves {p['coarse'][1]} x [Galerkin correction on "
+                                  f"{p['coarse'][0].shape[1]} multilinear coarse functions + "
+                                  f"Chebyshev sweeps {p['schur']}]" if p.get("coarse") else
+                                  f"Schur Chebyshev {p['schur']}") + " (its, emin, emax)"),
             "parallelism": f"time-block rows over {world} GPU(s)",
             "transport": (getattr(comm, "name", "rccl") if world > 1 else "none"),
             "sweep_tiles": ("boxes from the dof coordinates (kkt_set_tile_coordinates)"

@@ -2167,6 +2167,171 @@ void launch_vals_sym_skew(hipStream_t s, const double *a, const int32_t *tpos, d
                        nonsym);
 }
 
+// ---- coarse correction of the two-grid sub-solves (plain-launch form): r_c = P^T r,
+// e_c = E^-1 r_c, x_out = x_in + P e_c.  Fixed summation orders (no atomics): a workgroup per
+// coarse function sums its column of P in a fixed tree; a workgroup per row of E^-1 its row.
+__global__ __launch_bounds__(256) void coarse_restrict_kernel(
+    const int32_t *__restrict__ pt_ip, const int32_t *__restrict__ pt_ix,
+    const double *__restrict__ pt_v, const double *__restrict__ r, double *__restrict__ rc,
+    int stride) {
+    __shared__ double sh[256];
+    const int j = blockIdx.x;
+    double a = 0.0;
+    for (int32_t q = pt_ip[j] + threadIdx.x; q < pt_ip[j + 1]; q += 256)
+        a = __builtin_fma(pt_v[q], r[pt_ix[q]], a);
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) rc[(size_t)j * stride] = sh[0];
+}
+__global__ __launch_bounds__(256) void coarse_dense_kernel(const double *__restrict__ einv,
+                                                           const double *__restrict__ rc,
+                                                           double *__restrict__ ec, int nc) {
+    __shared__ double sh[256];
+    const int j = blockIdx.x;
+    const double *row = einv + (size_t)j * nc;
+    double a = 0.0;
+    for (int k = threadIdx.x; k < nc; k += 256) a = __builtin_fma(row[k], rc[k], a);
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ec[j] = sh[0];
+}
+__global__ void coarse_prolong_kernel(const int32_t *__restrict__ p_ip,
+                                      const int32_t *__restrict__ p_ix,
+                                      const double *__restrict__ p_v,
+                                      const double *__restrict__ ec,
+                                      const double *__restrict__ x_in, double *__restrict__ x_out,
+                                      int64_t n) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n;
+         r += (int64_t)gridDim.x * blockDim.x) {
+        double a = 0.0;
+        for (int32_t q = p_ip[r]; q < p_ip[r + 1]; ++q) a = __builtin_fma(p_v[q], ec[p_ix[q]], a);
+        x_out[r] = x_in ? x_in[r] + a : a;
+    }
+}
+void launch_coarse_correction(hipStream_t s, const CoarseDev &c, const double *einv,
+                              const double *r, const double *x_in, double *x_out, int64_t n) {
+    if (c.nc <= 0) return;
+    hipLaunchKernelGGL(coarse_restrict_kernel, dim3(c.nc), dim3(256), 0, s, c.pt_ip, c.pt_ix, c.pt_v,
+                       r, c.rc, 1);
+    hipLaunchKernelGGL(coarse_dense_kernel, dim3(c.nc), dim3(256), 0, s, einv, c.rc, c.ec, c.nc);
+    hipLaunchKernelGGL(coarse_prolong_kernel, dim3(grid_for(n)), dim3(256), 0, s, c.p_ip, c.p_ix,
+                       c.p_v, c.ec, x_in, x_out, n);
+}
+// set-up: x = column k of P (dense), and one restricted column of A P into E (column-major scratch)
+__global__ void coarse_column_kernel(const int32_t *__restrict__ pt_ip,
+                                     const int32_t *__restrict__ pt_ix,
+                                     const double *__restrict__ pt_v, int k,
+                                     double *__restrict__ x) {
+    for (int32_t q = pt_ip[k] + blockIdx.x * blockDim.x + threadIdx.x; q < pt_ip[k + 1];
+         q += gridDim.x * blockDim.x)
+        x[pt_ix[q]] = pt_v[q];
+}
+void launch_coarse_column(hipStream_t s, const CoarseDev &c, int k, double *x, int64_t n) {
+    launch_zero_bytes(s, x, (size_t)n * sizeof(double));
+    hipLaunchKernelGGL(coarse_column_kernel, dim3(8), dim3(256), 0, s, c.pt_ip, c.pt_ix, c.pt_v, k, x);
+}
+void launch_coarse_restrict(hipStream_t s, const CoarseDev &c, const double *r, double *rc,
+                            int stride) {
+    hipLaunchKernelGGL(coarse_restrict_kernel, dim3(c.nc), dim3(256), 0, s, c.pt_ip, c.pt_ix, c.pt_v,
+                       r, rc, stride);
+}
+
+// Dense inverse by Gauss-Jordan with partial pivoting on the device (set-up of the two-grid
+// sub-solves: (P^T A P)^-1, n up to a few thousand).  Three small launches per pivot, every sum
+// in a fixed order.  a (n x n, row-major) is destroyed; inv receives the inverse; *flag != 0:
+// singular.
+__global__ __launch_bounds__(256) void gj_pivot_kernel(const double *__restrict__ a, int n, int c,
+                                                       int *__restrict__ piv,
+                                                       double *__restrict__ pivval,
+                                                       unsigned *__restrict__ flag) {
+    __shared__ double bv[256];
+    __shared__ int bi[256];
+    double best = -1.0;
+    int at = c;
+    for (int r = c + (int)threadIdx.x; r < n; r += 256) {
+        const double v = fabs(a[(size_t)r * n + c]);
+        if (v > best) {
+            best = v;
+            at = r;
+        }
+    }
+    bv[threadIdx.x] = best;
+    bi[threadIdx.x] = at;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            const double o = bv[threadIdx.x + st];
+            const int oi = bi[threadIdx.x + st];
+            if (o > bv[threadIdx.x] || (o == bv[threadIdx.x] && oi < bi[threadIdx.x])) {
+                bv[threadIdx.x] = o;
+                bi[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        piv[0] = bi[0];
+        pivval[0] = a[(size_t)bi[0] * n + c];
+        if (!(bv[0] > 0.0) || !isfinite(bv[0])) atomicOr(flag, 1u);
+    }
+}
+__global__ void gj_swap_scale_kernel(double *__restrict__ a, double *__restrict__ inv, int n, int c,
+                                     const int *__restrict__ piv, double *__restrict__ colbuf) {
+    const int p = piv[0];
+    const double d = colbuf[n];     // the pivot, saved by gj_pivot_kernel (this kernel overwrites it)
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < 2 * n;
+         j += gridDim.x * blockDim.x) {
+        double *m = j < n ? a : inv;
+        const int col = j < n ? j : j - n;
+        const double vp = m[(size_t)p * n + col], vc = m[(size_t)c * n + col];
+        m[(size_t)p * n + col] = vc;                     // row p <- old row c
+        m[(size_t)c * n + col] = d != 0.0 ? vp / d : 0.0;    // row c <- old row p, scaled
+    }
+}
+__global__ void gj_column_kernel(const double *__restrict__ a, int n, int c,
+                                 double *__restrict__ colbuf) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x)
+        colbuf[r] = r == c ? 0.0 : a[(size_t)r * n + c];
+}
+__global__ __launch_bounds__(256) void gj_eliminate_kernel(double *__restrict__ a,
+                                                           double *__restrict__ inv, int n, int c,
+                                                           const double *__restrict__ colbuf) {
+    const int r = blockIdx.y;
+    const double f = colbuf[r];
+    if (f == 0.0) return;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < 2 * n; j += gridDim.x * blockDim.x) {
+        double *m = j < n ? a : inv;
+        const int col = j < n ? j : j - n;
+        m[(size_t)r * n + col] -= f * m[(size_t)c * n + col];
+    }
+}
+__global__ void gj_identity_kernel(double *__restrict__ inv, int n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n * n;
+         i += (size_t)gridDim.x * blockDim.x)
+        inv[i] = (i / n == i % n) ? 1.0 : 0.0;
+}
+void launch_dense_inverse(hipStream_t s, double *a, double *inv, int n, int *d_piv,
+                          double *d_colbuf, unsigned *d_flag) {
+    hipLaunchKernelGGL(gj_identity_kernel, dim3(grid_for((int64_t)n * n)), dim3(256), 0, s, inv, n);
+    const dim3 g1(grid_for(2 * n, 256, 64));
+    const dim3 ge(grid_for(2 * n, 256, 8), n);
+    for (int c = 0; c < n; ++c) {
+        hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(256), 0, s, a, n, c, d_piv, d_colbuf + n,
+                           d_flag);
+        hipLaunchKernelGGL(gj_swap_scale_kernel, g1, dim3(256), 0, s, a, inv, n, c, d_piv, d_colbuf);
+        hipLaunchKernelGGL(gj_column_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, n, c, d_colbuf);
+        hipLaunchKernelGGL(gj_eliminate_kernel, ge, dim3(256), 0, s, a, inv, n, c, d_colbuf);
+    }
+}
+
 // the time-out word of the sweep programs as a summand of the Krylov all-reduce (time shards)
 __global__ void flag_to_double_kernel(const unsigned *flag, double *out) {
     out[0] = (flag != nullptr && flag[0] != 0u) ? 1.0 : 0.0;

@@ -126,7 +126,34 @@ struct alignas(128) TileLevel {
     double post1, post2;       // factors of the last step
     const TileCoef *coef;      // steps 2 .. its: p_s = c1 p_{s-2} + c2 p_{s-1} + c3 dinv (b - F p_{s-1})
 };
+// Coarse corrections inside the tile program (two-grid form of the sub-solves): what a tile needs
+// to restrict its own rows' residual to the coarse functions they touch (J_t), to publish those
+// partial sums, to assemble the whole coarse residual from every tile's partials in a fixed order,
+// to apply its rows of (P^T A P)^-1 and to prolong onto its own rows.  Device-resident plan,
+// built by SchurPC from the tile plan and P (csrc/pc.cpp, build_tile_coarse).
+struct TileCoarseDev {
+    int32_t nc, jmax, n0max, nslots;
+    int32_t nr_max;               // most restriction (= prolongation) entries of a tile
+    const int32_t *nj;            // [ntiles] number of coarse functions the own rows touch
+    const int32_t *jglob;         // [ntiles][jmax] their global numbers
+    const int32_t *slot0;         // [ntiles] first slot of the tile's partial sums
+    const int32_t *r_ip;          // [ntiles * jmax + 1] restriction lists, per (tile, k) ...
+    const uint16_t *r_row;        // ... local own row
+    const double *r_w;            // ... and weight, ascending rows
+    const int32_t *p_ip;          // [ntiles * n0max + 1] prolongation entries of the own rows ...
+    const uint16_t *p_k;          // ... index into the tile's J_t
+    const double *p_w;
+    const int32_t *c_ip;          // [nc + 1] slots that contribute to a coarse function ...
+    const int32_t *c_slot;        // ... ascending (tile order)
+    unsigned long long *cg[2];    // granule buffers of the partial sums, 2 words per slot
+    uint32_t cg_bytes;
+};
+constexpr int TILE_COARSE_SLOTS = 8;   // partial-sum slots polled per thread, at most
 struct TileArgs {
+    const TileCoarseDev *coarse;              // null: plain Chebyshev levels
+    const double *const *einv;                // per level: (P^T A P)^-1 of the level's matrix
+    int32_t cycles;                           // coarse cycles per level (its = sweeps per cycle)
+    uint32_t cepoch0;                         // coarse exchanges of this launch carry tags cepoch0 + 1, ...
     int32_t nlevels, its, depth, nk_pad, rpt, W;
     unsigned long long *gnew[2], *gold[2];   // granule buffers, 2 words per row each
     unsigned granule_bytes;
@@ -142,18 +169,21 @@ struct TileArgs {
     int32_t hslots;                           // ring-entry slots per thread the plan needs
 };
 bool tile_sweep_available(int W, int rpt, int threads, int hslots);   // hslots: ring-entry slots per thread
+bool tile_sweep_coarse_available(int W, int rpt, int threads, int hslots);   // variant with coarse corrections
 int tile_sweep_max_hslots(int W, int rpt, int threads);
 int tile_sweep_max_rpt(int W, int threads);   // most row slots per thread of any variant (0: none)
 // whether the variant for this shape computes the level update b -= U u_prev itself (narrow
 // rows); wide rows (3-D P1) have no registers for it: the update stays a launch of its own
 bool tile_sweep_fuses_update(int W, int max_terms);   // update terms of any level of the run
-size_t tile_sweep_lds_bytes(int nk_pad, int its);
+size_t tile_sweep_lds_bytes(int nk_pad, int its, int coarse_nc = 0, int coarse_nslots = 0,
+                            int coarse_jmax = 0, int coarse_nr_max = 0);
 // workgroups of `threads` that are certainly co-resident (one per CU)
-int tile_sweep_max_tiles(int W, int rpt, int threads, size_t lds_bytes, int hslots);
+int tile_sweep_max_tiles(int W, int rpt, int threads, size_t lds_bytes, int hslots,
+                         bool coarse = false);
 void launch_tile_sweep(hipStream_t s, const TileArgs &a, const TileLevel *d_levels,
                        const int32_t *d_n, const int32_t *d_grow, const uint16_t *d_lcol,
                        const int32_t *d_gpos, const uint8_t *d_rowmask, int ntiles, int threads,
-                       size_t granule_words);
+                       size_t granule_words, const TileCoarseDev *h_coarse = nullptr);
 
 // ---- value-array preparation
 void launch_csr_to_sell(hipStream_t s, const double *csr_vals, const int32_t *sell2csr,
@@ -211,6 +241,26 @@ void launch_mdot(hipStream_t s, const double *w, VecList V, int nv, int64_t n,
 // out[0] = sqrt(<w, w> + extra) where extra = (add ? *add : 0)
 void launch_norm2_finish(hipStream_t s, const double *dot, double *out);
 void launch_zero_bytes(hipStream_t s, void *p, size_t nbytes);   // kernel node, not a memset node
+
+// ---- coarse space of the two-grid sub-solves on the device: P by rows (prolongation) and by
+// columns (restriction), scratch for one correction
+struct CoarseDev {
+    int nc = 0;
+    const int32_t *p_ip = nullptr, *p_ix = nullptr;     // P: n rows
+    const double *p_v = nullptr;
+    const int32_t *pt_ip = nullptr, *pt_ix = nullptr;   // P^T: nc rows
+    const double *pt_v = nullptr;
+    double *rc = nullptr, *ec = nullptr;                // nc doubles each
+};
+// x_out = x_in + P E^-1 P^T r (x_in may be null or x_out); three launches, fixed summation orders
+void launch_coarse_correction(hipStream_t s, const CoarseDev &c, const double *einv,
+                              const double *r, const double *x_in, double *x_out, int64_t n);
+void launch_coarse_column(hipStream_t s, const CoarseDev &c, int k, double *x, int64_t n);
+void launch_coarse_restrict(hipStream_t s, const CoarseDev &c, const double *r, double *rc,
+                            int stride = 1);
+// inv = a^-1 (n x n row-major, a destroyed) by Gauss-Jordan with partial pivoting on the device
+void launch_dense_inverse(hipStream_t s, double *a, double *inv, int n, int *d_piv,
+                          double *d_colbuf, unsigned *d_flag);
 void launch_flag_to_double(hipStream_t s, const unsigned *flag, double *out);
 // w += sign * sum_i coef[i] * V_i   (coef in device memory)
 void launch_maxpy(hipStream_t s, double *w, VecList V, const double *coef, double sign,

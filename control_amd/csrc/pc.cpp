@@ -39,6 +39,24 @@ SchurPC::SchurPC(System &S, const kkt_pc_desc &d) : S_(S), d_(d) {
     m_indices_.assign(d.m_indices, d.m_indices + m_indptr_[nx_]);
     m_values_.assign(d.m_values, d.m_values + m_indptr_[nx_]);
     if (d.n_bc > 0) bc_idx_.assign(d.bc_idx, d.bc_idx + d.n_bc);
+    if (d.coarse_cycles < 0) fail(KKT_ERR_ARG, "negative number of coarse cycles");
+    if (d.coarse_cycles > 0) {
+        if (!d.p_indptr || !d.p_indices || !d.p_values || d.n_coarse < 1)
+            fail(KKT_ERR_ARG, "coarse_cycles > 0 needs the prolongation matrix P");
+        if (d.n_coarse > 4096) fail(KKT_ERR_ARG, "coarse space too large (dense inverse): n_coarse <= 4096");
+        coarse_cycles_ = d.coarse_cycles;
+        p_indptr_.assign(d.p_indptr, d.p_indptr + nx_ + 1);
+        const int64_t pn = p_indptr_[nx_];
+        if (p_indptr_[0] != 0 || pn < 0) fail(KKT_ERR_ARG, "bad P indptr");
+        p_indices_.assign(d.p_indices, d.p_indices + pn);
+        p_values_.assign(d.p_values, d.p_values + pn);
+        for (int64_t r = 0; r < nx_; ++r)
+            if (p_indptr_[r + 1] < p_indptr_[r]) fail(KKT_ERR_ARG, "P indptr not monotone");
+        for (int32_t c : p_indices_)
+            if (c < 0 || c >= d.n_coarse) fail(KKT_ERR_ARG, "P column index out of range");
+    }
+    d_.p_indptr = d_.p_indices = nullptr;
+    d_.p_values = nullptr;
     d_.m_indptr = d_.m_indices = nullptr;
     d_.m_values = nullptr;
     d_.bc_idx = nullptr;
@@ -60,6 +78,7 @@ SchurPC::~SchurPC() {
     if (side_) (void)hipStreamDestroy(side_);
     for (void *p : owned_)
         if (p) (void)hipFree(p);
+    for (double *p : einv_owned_) (void)hipFree(p);
 }
 
 void SchurPC::clear_program() {
@@ -108,6 +127,8 @@ void SchurPC::values_changed() {
         (void)hipFree(kv.second.dinv);
     }
     mats_.clear();
+    for (double *p : einv_owned_) (void)hipFree(p);
+    einv_owned_.clear();
     if (d_.kind == KKT_PC_STATIONARY)
         build_stationary();
     else if (d_.kind == KKT_PC_INSTATIONARY_BE)
@@ -335,9 +356,19 @@ bool SchurPC::prepare_tiles() {
     // (solo levels of the stationary preconditioner run with mass_its, which may exceed schur_its_)
     int max_its = std::max(schur_its_, 2);
     for (const SweepLevel &lv : sweep_levels_) max_its = std::max(max_its, lv.its);
-    const size_t lds = tile_sweep_lds_bytes(tp.nk_pad, max_its);
+    size_t lds = tile_sweep_lds_bytes(tp.nk_pad, max_its);
     if (tp.ntiles > tile_sweep_max_tiles(tp.W, tp.rpt, threads, lds, tp.hslots)) return false;
     tile_lds_checked_ = lds;
+    // two-grid levels: the variant with coarse corrections and its larger LDS footprint
+    tile_coarse_ok_ = false;
+    if (coarse_cycles_ > 0 && tile_sweep_coarse_available(tp.W, tp.rpt, threads, tp.hslots) &&
+        build_tile_coarse()) {
+        const size_t lds_c = tile_sweep_lds_bytes(tp.nk_pad, max_its, h_tile_coarse_.nc,
+                                                  h_tile_coarse_.nslots, h_tile_coarse_.jmax,
+                                                  h_tile_coarse_.nr_max);
+        tile_coarse_ok_ = lds_c <= 160 * 1024 &&
+                          tp.ntiles <= tile_sweep_max_tiles(tp.W, tp.rpt, threads, lds_c, tp.hslots, true);
+    }
     tp.upload();
     const size_t words = 2 * (size_t)P.nrows;
     for (int i = 0; i < 4; ++i) {
@@ -351,6 +382,114 @@ bool SchurPC::prepare_tiles() {
                      threads, tp.depth, tp.W, tp.rpt, (long long)tp.max_own, (long long)tp.max_rows,
                      (long long)tp.max_halo, tp.mean_redundancy, tp.model_us);
     tile_ok_ = true;
+    return true;
+}
+
+// Coarse corrections inside the tile program: per tile, the coarse functions its own rows touch
+// (J_t) with their restriction lists, the prolongation entries of its own rows, the slots of its
+// partial sums; per coarse function, the slots that contribute to it (ascending tile order).
+bool SchurPC::build_tile_coarse() {
+    const TilePlan &tp = tile_plan_;
+    const int nt = tp.ntiles, nc = coarse_.nc;
+    if (nt < 1 || nc < 1) return false;
+    std::vector<int32_t> nj(nt, 0), slot0(nt, 0);
+    std::vector<std::vector<int32_t>> J(nt);
+    int n0max = 0;
+    for (int t = 0; t < nt; ++t) {
+        const int n0 = tp.n[(size_t)t * (TILE_MAX_DEPTH + 1)];
+        n0max = std::max(n0max, n0);
+        std::vector<int32_t> &j = J[t];
+        for (int l = 0; l < n0; ++l) {
+            const int32_t g = tp.grow[(size_t)t * tp.nk_pad + l];
+            for (int32_t q = p_indptr_[g]; q < p_indptr_[g + 1]; ++q) j.push_back(p_indices_[q]);
+        }
+        std::sort(j.begin(), j.end());
+        j.erase(std::unique(j.begin(), j.end()), j.end());
+        nj[t] = (int32_t)j.size();
+    }
+    int jmax = 0, nslots = 0;
+    for (int t = 0; t < nt; ++t) {
+        jmax = std::max(jmax, nj[t]);
+        slot0[t] = nslots;
+        nslots += nj[t];
+    }
+    if (jmax < 1 || jmax > 65535 || nslots > 65536) return false;
+    std::vector<int32_t> jglob((size_t)nt * jmax, -1), r_ip((size_t)nt * jmax + 1, 0),
+        p_ip((size_t)nt * n0max + 1, 0), c_ip(nc + 1, 0), c_slot;
+    std::vector<uint16_t> r_row, p_k;
+    std::vector<double> r_w, p_w;
+    std::vector<std::vector<int32_t>> contrib(nc);
+    for (int t = 0; t < nt; ++t) {
+        const int n0 = tp.n[(size_t)t * (TILE_MAX_DEPTH + 1)];
+        const std::vector<int32_t> &j = J[t];
+        std::vector<std::vector<std::pair<uint16_t, double>>> lists(j.size());
+        for (int l = 0; l < n0; ++l) {
+            const int32_t g = tp.grow[(size_t)t * tp.nk_pad + l];
+            for (int32_t q = p_indptr_[g]; q < p_indptr_[g + 1]; ++q) {
+                const int k = (int)(std::lower_bound(j.begin(), j.end(), p_indices_[q]) - j.begin());
+                lists[k].push_back({(uint16_t)l, p_values_[q]});
+                p_k.push_back((uint16_t)k);
+                p_w.push_back(p_values_[q]);
+            }
+            p_ip[(size_t)t * n0max + l + 1] = (int32_t)p_k.size();
+        }
+        for (int l = n0; l < n0max; ++l) p_ip[(size_t)t * n0max + l + 1] = (int32_t)p_k.size();
+        for (size_t k = 0; k < (size_t)jmax; ++k) {
+            if (k < j.size()) {
+                jglob[(size_t)t * jmax + k] = j[k];
+                contrib[j[k]].push_back(slot0[t] + (int)k);
+                for (auto &e : lists[k]) {
+                    r_row.push_back(e.first);
+                    r_w.push_back(e.second);
+                }
+            }
+            r_ip[(size_t)t * jmax + k + 1] = (int32_t)r_row.size();
+        }
+    }
+    for (int j = 0; j < nc; ++j) {
+        for (int32_t sl : contrib[j]) c_slot.push_back(sl);
+        c_ip[j + 1] = (int32_t)c_slot.size();
+    }
+    auto up = [&](const auto &v) {
+        auto *p = dev_upload(v.data(), std::max<size_t>(1, v.size()));
+        owned_.push_back((void *)p);
+        return p;
+    };
+    TileCoarseDev &D = h_tile_coarse_;
+    D.nc = nc;
+    D.jmax = jmax;
+    D.n0max = n0max;
+    D.nslots = nslots;
+    {
+        int nrm = 1;
+        for (int t = 0; t < nt; ++t)
+            nrm = std::max(nrm, r_ip[(size_t)t * jmax + nj[t]] - r_ip[(size_t)t * jmax]);
+        D.nr_max = nrm;
+    }
+    D.nj = up(nj);
+    D.jglob = up(jglob);
+    D.slot0 = up(slot0);
+    D.r_ip = up(r_ip);
+    if (r_row.empty()) r_row.push_back(0), r_w.push_back(0.0);
+    D.r_row = up(r_row);
+    D.r_w = up(r_w);
+    D.p_ip = up(p_ip);
+    if (p_k.empty()) p_k.push_back(0), p_w.push_back(0.0);
+    D.p_k = up(p_k);
+    D.p_w = up(p_w);
+    D.c_ip = up(c_ip);
+    D.c_slot = up(c_slot);
+    D.cg_bytes = (uint32_t)((size_t)nslots * 16);
+    for (int i = 0; i < 2; ++i) {
+        D.cg[i] = dev_alloc<unsigned long long>((size_t)nslots * 2);
+        HIPCHK(hipMemset(D.cg[i], 0, D.cg_bytes));
+        owned_.push_back(D.cg[i]);
+    }
+    d_tile_coarse_ = dev_upload(&D, 1);
+    owned_.push_back(d_tile_coarse_);
+    if (S_.opt("verbose"))
+        std::fprintf(stderr, "[kkt] tile sweep program, coarse corrections: %d coarse functions, at most "
+                     "%d per tile, %d partial-sum slots\n", nc, jmax, nslots);
     return true;
 }
 
@@ -369,12 +508,19 @@ bool SchurPC::fuse_tile_run(size_t k, size_t e, std::vector<PcStep> &out) {
     }
     if (run.empty()) return false;
     const int its = run[0]->its;
+    const bool coarse = run[0]->coarse;
+    if (coarse && !tile_coarse_ok_) return false;
     {
         // residency and the dynamic-LDS attribute were checked for tile_lds_checked_ bytes
-        const size_t need = tile_sweep_lds_bytes(tile_plan_.nk_pad, its);
+        const size_t need = coarse ? tile_sweep_lds_bytes(tile_plan_.nk_pad, its, h_tile_coarse_.nc,
+                                                          h_tile_coarse_.nslots, h_tile_coarse_.jmax,
+                                                          h_tile_coarse_.nr_max)
+                                   : tile_sweep_lds_bytes(tile_plan_.nk_pad, its);
         if (need > tile_lds_checked_) {
-            if (tile_plan_.ntiles > tile_sweep_max_tiles(tile_plan_.W, tile_plan_.rpt,
-                                                         tile_plan_.threads, need, tile_plan_.hslots))
+            if (need > 160 * 1024 ||
+                tile_plan_.ntiles > tile_sweep_max_tiles(tile_plan_.W, tile_plan_.rpt,
+                                                         tile_plan_.threads, need, tile_plan_.hslots,
+                                                         coarse))
                 return false;
             tile_lds_checked_ = need;
         }
@@ -382,7 +528,9 @@ bool SchurPC::fuse_tile_run(size_t k, size_t e, std::vector<PcStep> &out) {
     std::vector<TileLevel> levels;
     for (size_t i = 0; i < run.size(); ++i) {
         const SweepLevel &lv = *run[i];
-        if (lv.its != its || (int)lv.coef.size() != its - 1) return false;
+        if (lv.its != its || lv.coarse != coarse ||
+            (int)lv.coef.size() != (coarse ? its : its - 1))
+            return false;
         TileLevel L = lv.lev;
         L.prev_in_lds = 0;
         // operands read from plain memory must not be produced inside this launch
@@ -409,11 +557,23 @@ bool SchurPC::fuse_tile_run(size_t k, size_t e, std::vector<PcStep> &out) {
         L.coef = d_coef;
         levels.push_back(L);
     }
-    const int per_launch = its / std::max(1, tile_plan_.depth) + 2;   // hand-offs of a level, at most
+    // hand-offs of a level, at most (two-grid levels: per cycle one after the correction, one in
+    // front of the residual, those of the sweeps; one at the level's end)
+    const int per_launch = coarse ? coarse_cycles_ * (its / std::max(1, tile_plan_.depth) + 3) + 2
+                                  : its / std::max(1, tile_plan_.depth) + 2;
+    std::vector<const double *> einvs;
+    for (const SweepLevel *lv : run) einvs.push_back(lv->einv);
     auto tile_step = [&](const TileLevel *lv, int n, int nphases, bool fused) {
         PcStep s;
         s.kind = PcStep::TILE;
         s.fused = fused;
+        s.coarse = coarse;
+        if (coarse) {
+            s.d_einv = dev_upload(einvs.data(), einvs.size());
+            tile_owned_.push_back((void *)s.d_einv);
+            s.cepoch0 = tile_cepoch_cursor_;
+            tile_cepoch_cursor_ += (uint32_t)(n * coarse_cycles_);
+        }
         s.d_levels = dev_upload(lv, (size_t)n);
         s.nlevels = n;
         s.its = its;
@@ -426,8 +586,9 @@ bool SchurPC::fuse_tile_run(size_t k, size_t e, std::vector<PcStep> &out) {
     };
     int max_terms = 0;
     for (const TileLevel &L : levels) max_terms = std::max(max_terms, (int)L.n_upd);
+    if (coarse && !tile_sweep_fuses_update(tile_plan_.W, max_terms)) return false;
     if (tile_sweep_fuses_update(tile_plan_.W, max_terms) &&
-        !(tile_plan_.W > 9 && S_.opt("tile_unfused"))) {
+        !(tile_plan_.W > 9 && S_.opt("tile_unfused") && !coarse)) {
         for (size_t q = k; q < e; ++q) (void)hipFree(steps_[q].rows.d_ops);
         tile_step(levels.data(), (int)levels.size(), (int)(e - k), true);
         return true;
@@ -469,6 +630,7 @@ void SchurPC::fuse_programs() {
     const bool tile_wanted = tile_forced || !pm_all || pm_all[0] == 'a';
     const bool use_tiles = tile_wanted && prepare_tiles();
     tile_epoch_cursor_ = 0;
+    tile_cepoch_cursor_ = 0;
     tile_cleared_ = false;
     if (!legacy_tried_) {
         legacy_tried_ = true;
@@ -541,12 +703,23 @@ void SchurPC::fuse_programs() {
     size_t k = 0;
     while (k < steps_.size()) {
         size_t e = k;
-        while (e < steps_.size() && steps_[e].kind == PcStep::ROWS && steps_[e].rows.nops == 1) ++e;
+        bool has_coarse = false;
+        // (the coarse corrections of two-grid levels sit between the single-block steps)
+        while (e < steps_.size() && ((steps_[e].kind == PcStep::ROWS && steps_[e].rows.nops == 1) ||
+                                     steps_[e].kind == PcStep::COARSE)) {
+            has_coarse = has_coarse || steps_[e].kind == PcStep::COARSE;
+            ++e;
+        }
         if (e == k) {
             out.push_back(steps_[k++]);
             continue;
         }
         if (e - k >= 4 && use_tiles && fuse_tile_run(k, e, out)) {
+            k = e;
+            continue;
+        }
+        if (has_coarse) {      // two-grid levels outside the tile form stay plain launches
+            for (size_t i = k; i < e; ++i) out.push_back(steps_[i]);
             k = e;
             continue;
         }
@@ -768,6 +941,10 @@ void SchurPC::build() {
     h_u0_ = vec(1);
     h_u1_ = vec(1);
     h_t_ = vec(1);
+    if (coarse_cycles_ > 0) {
+        R_ = vec(1);
+        build_coarse();
+    }
     values_changed();
 }
 
@@ -794,6 +971,213 @@ const int32_t *SchurPC::transpose_positions() {
     return d_tpos_;
 }
 
+// ---- two-grid form of the sub-solves: coarse space on the device, Galerkin inverses
+void SchurPC::build_coarse() {
+    const int nc = (int)d_.n_coarse;
+    // P^T by a counting sort over the columns (entries of a column in ascending row order: the
+    // restriction sums them in that order)
+    pt_indptr_.assign(nc + 1, 0);
+    for (int32_t c : p_indices_) pt_indptr_[c + 1]++;
+    for (int j = 0; j < nc; ++j) pt_indptr_[j + 1] += pt_indptr_[j];
+    pt_indices_.resize(p_indices_.size());
+    pt_values_.resize(p_indices_.size());
+    std::vector<int32_t> cur(pt_indptr_.begin(), pt_indptr_.end() - 1);
+    for (int64_t r = 0; r < nx_; ++r)
+        for (int32_t q = p_indptr_[r]; q < p_indptr_[r + 1]; ++q) {
+            const int32_t at = cur[p_indices_[q]]++;
+            pt_indices_[at] = (int32_t)r;
+            pt_values_[at] = p_values_[q];
+        }
+    auto up = [&](const auto &v) {
+        auto *p = dev_upload(v.data(), v.size());
+        owned_.push_back((void *)p);
+        return p;
+    };
+    coarse_.nc = nc;
+    coarse_.p_ip = up(p_indptr_);
+    coarse_.p_ix = up(p_indices_);
+    coarse_.p_v = up(p_values_);
+    coarse_.pt_ip = up(pt_indptr_);
+    coarse_.pt_ix = up(pt_indices_);
+    coarse_.pt_v = up(pt_values_);
+    coarse_.rc = dev_alloc<double>(nc);
+    coarse_.ec = dev_alloc<double>(nc);
+    owned_.push_back(coarse_.rc);
+    owned_.push_back(coarse_.ec);
+}
+
+// E = P^T A P column by column with the kernels the sweeps use (x = column k of P, y = A x with
+// the boundary rows masked, E(:, k) = P^T y: fixed summation orders, so every rank and every run
+// forms the same matrix), inverted on the device by Gauss-Jordan with partial pivoting.
+double *SchurPC::coarse_inverse(const double *vals) {
+    const Pattern &P = S_.patterns[m_pat_];
+    hipStream_t st = S_.stream;
+    const int nc = coarse_.nc;
+    double *x = dev_alloc<double>(nx_ + 32), *y = dev_alloc<double>(nx_ + 32);
+    double *E = dev_alloc<double>((size_t)nc * nc);
+    auto vref = [](const double *q) { return q ? VRef{(int64_t)(uintptr_t)q, 0, 0} : VRef{0, -1, 0}; };
+    RowOp op{};
+    op.col = P.d_col;
+    op.perm = P.d_perm;
+    op.slice_off = P.d_slice_off;
+    op.uniform_w = P.uniform_w;
+    op.nrows = (int32_t)nx_;
+    op.nslices = P.nslices;
+    op.nterms = 1;
+    op.mode = EPI_LIN;
+    op.t[0].vals = vals;
+    op.t[0].x = vref(x);
+    op.y = vref(y);
+    op.y2 = op.yin = op.z = op.mx = op.b = op.pk = op.pkm1 = vref(nullptr);
+    op.ca = 1.0;
+    op.rowmask = mask_;
+    RowOp *d_op = dev_upload(&op, 1);
+    const Bases B{{nullptr, nullptr, nullptr, nullptr}};
+    for (int k = 0; k < nc; ++k) {
+        launch_coarse_column(st, coarse_, k, x, nx_);
+        launch_rowops(st, d_op, 1, P.nslices, P.R, B, 1, P.uniform_w);
+        launch_coarse_restrict(st, coarse_, y, E + k, nc);     // column k of the row-major E
+    }
+    double *d_inv = dev_alloc<double>((size_t)nc * nc);
+    int *d_piv = dev_alloc<int>(1);
+    double *d_colbuf = dev_alloc<double>(nc + 1);     // multipliers; slot nc: the pivot
+    unsigned *d_flag = dev_alloc<unsigned>(1);
+    HIPCHK(hipMemsetAsync(d_flag, 0, sizeof(unsigned), st));
+    launch_dense_inverse(st, E, d_inv, nc, d_piv, d_colbuf, d_flag);
+    unsigned singular = 0;
+    HIPCHK(hipMemcpyAsync(&singular, d_flag, sizeof singular, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    (void)hipFree(x);
+    (void)hipFree(y);
+    (void)hipFree(E);
+    (void)hipFree(d_op);
+    (void)hipFree(d_piv);
+    (void)hipFree(d_colbuf);
+    (void)hipFree(d_flag);
+    if (singular) {
+        (void)hipFree(d_inv);
+        fail(KKT_ERR_STATE, "coarse matrix P^T A P is singular (a coarse function without support on "
+                            "free rows, or dependent coarse functions)");
+    }
+    einv_owned_.push_back(d_inv);
+    return d_inv;
+}
+
+void SchurPC::emit_coarse(const double *r, const double *x_in, double *x_out, const double *einv) {
+    PcStep s;
+    s.kind = PcStep::COARSE;
+    s.cr = r;
+    s.x = x_in;
+    s.y = x_out;
+    s.einv = einv;
+    s.nx = nx_;
+    s.lane = cur_lane_;
+    steps_.push_back(s);
+}
+
+// coefficients (c1, c2, c3) of the Chebyshev steps 2 .. its (what emit_solves generates)
+static std::vector<TileCoef> cheb_coefficients(int its, double emin, double emax, double eimag) {
+    std::vector<TileCoef> out;
+    const double scale = 2.0 / (emax + emin);
+    const double alpha = 1.0 - scale * emin;
+    const double mu = 1.0 / alpha, omegaprod = 2.0 / alpha;
+    double c_km1 = 1.0, c_k = mu;
+    const double ell_d = 0.5 * (emax + emin), ell_a = 0.5 * (emax - emin);
+    const double ell_c2 = ell_a * ell_a - eimag * eimag;
+    double ell_alpha = 1.0 / ell_d;
+    for (int step = 2; step <= its; ++step) {
+        if (eimag > 0.0) {
+            ell_alpha = 1.0 / (ell_d - (step == 2 ? 0.5 : 0.25) * ell_c2 * ell_alpha);
+            const double beta = ell_d * ell_alpha - 1.0;
+            out.push_back(TileCoef{-beta, 1.0 + beta, ell_alpha});
+        } else {
+            const double c_kp1 = 2.0 * mu * c_k - c_km1;
+            const double omega = omegaprod * c_k / c_kp1;
+            out.push_back(TileCoef{1.0 - omega, omega, scale * omega});
+            c_km1 = c_k;
+            c_k = c_kp1;
+        }
+    }
+    return out;
+}
+
+// One sub-solve in its two-grid form: [update of the right-hand side;] cycles x [Galerkin
+// correction of the current iterate; `its` smoothing sweeps from it].
+void SchurPC::emit_coarse_solve(const Lin *upd, const Solve &sv, const Mat &F) {
+    const int its = std::max(1, schur_its_);
+    SweepLevel lv;
+    lv.first = steps_.size();
+    if (upd) {
+        Lin u = *upd;
+        u.y2 = nullptr;
+        emit_lin({u});
+    }
+    const double scale = 2.0 / (F.emax + F.emin);
+    const std::vector<TileCoef> coef = cheb_coefficients(its, F.emin, F.emax, F.eimag);
+    {
+        // what the tile form runs as one two-grid level
+        lv.its = its;
+        lv.coarse = true;
+        lv.einv = F.einv;
+        lv.coef.push_back(TileCoef{0.0, 1.0, scale});
+        lv.coef.insert(lv.coef.end(), coef.begin(), coef.end());
+        TileLevel &L = lv.lev;
+        L.vals = F.vals;
+        L.dinv = F.dinv;
+        L.out = sv.out;
+        L.p1_scale = scale;
+        L.post1 = sv.post1;
+        L.post2 = sv.post2;
+        bool ok = true;
+        if (upd) {
+            ok = !upd->terms.empty() && upd->terms.size() <= 2 && upd->cz == 0.0 && !upd->z &&
+                 upd->yin != nullptr;
+            for (const Term &t : upd->terms) ok = ok && t.x == upd->terms[0].x;
+            if (ok) {
+                L.bin = upd->yin;
+                L.bout = upd->y == upd->yin ? nullptr : upd->y;
+                lv.b_after = upd->y;
+                L.x_prev = upd->terms[0].x;
+                L.n_upd = (int32_t)upd->terms.size();
+                for (size_t t = 0; t < upd->terms.size(); ++t) L.upd_vals[t] = upd->terms[t].vals;
+                L.ca = upd->ca;
+                L.cy = upd->cy;
+            }
+        } else {
+            L.bin = sv.b;
+            L.bout = nullptr;
+            L.n_upd = 0;
+        }
+        lv.eligible = ok;
+    }
+    double *p0 = P_[2];
+    const double *xcur = nullptr;
+    for (int c = 0; c < coarse_cycles_; ++c) {
+        const bool last_cycle = c + 1 == coarse_cycles_;
+        const double *r = sv.b;
+        if (c > 0) {
+            // r = b - F x
+            emit_lin({Lin{{Term{F.vals, xcur}}, R_, -1.0, 0.0, 1.0, nullptr, sv.b}});
+            r = R_;
+        }
+        emit_coarse(r, xcur, p0, F.einv);
+        auto target = [&](int step) -> double * {
+            return (last_cycle && step == its) ? sv.out : P_[(step - 1) % 3];
+        };
+        for (int step = 1; step <= its; ++step) {
+            const bool last = last_cycle && step == its;
+            const double *pk = step == 1 ? p0 : target(step - 1);
+            const double *pkm1 = step == 1 ? nullptr : (step == 2 ? p0 : target(step - 2));
+            const TileCoef k = step == 1 ? TileCoef{0.0, 1.0, scale} : coef[step - 2];
+            emit_cheb({Cheb{F.vals, F.dinv, sv.b, pk, pkm1, target(step), k.c1, k.c2, k.c3,
+                            last ? sv.post1 : 1.0, last ? sv.post2 : 1.0}});
+        }
+        xcur = target(its);
+    }
+    lv.last = steps_.size();
+    sweep_levels_.push_back(lv);
+}
+
 // base + c * M with bc rows/cols of `assemble(form, bcs=...)`, and its Jacobi diagonal
 SchurPC::Mat SchurPC::schur_matrix(const double *base_vals, double c) {
     uint64_t bits;
@@ -810,16 +1194,10 @@ SchurPC::Mat SchurPC::schur_matrix(const double *base_vals, double c) {
     if (mask_) launch_mask_columns(st, m.vals, P.d_col, mask_, P.npadded);
     launch_extract_dinv(st, P.d_col, P.d_slice_off, m.vals, mask_, m.dinv, (int)nx_, P.nslices,
                         P.R, P.d_perm);
-    if (d_.schur_emin > 0) {
-        m.emin = d_.schur_emin;
-        m.emax = d_.schur_emax;
-        m.eimag = d_.schur_eimag > 0 ? d_.schur_eimag : 0.0;
-    } else {
-        // Interval from the matrix itself.  Matrices with the same shift and the same values
-        // (mode G stores one copy per time level of a time-invariant operator) share one
-        // estimate; the first and last levels carry other shifts (control.py:2241-2327) and get
-        // their own, wider, intervals.
-        bool found = false;
+    // an earlier matrix with the same shift and the same values (mode G stores one copy per time
+    // level of a time-invariant operator) shares its spectrum estimate and its coarse inverse
+    const Mat *twin = nullptr;
+    if (d_.schur_emin <= 0 || coarse_cycles_ > 0) {
         for (auto &kv : mats_) {
             if (kv.first.second != bits || kv.second.emax <= 0.0) continue;
             unsigned *d_flag = dev_alloc<unsigned>(1);
@@ -830,46 +1208,58 @@ SchurPC::Mat SchurPC::schur_matrix(const double *base_vals, double c) {
             HIPCHK(hipStreamSynchronize(st));
             HIPCHK(hipFree(d_flag));
             if (!differ) {
-                m.emin = kv.second.emin;
-                m.emax = kv.second.emax;
-                m.eimag = kv.second.eimag;
-                found = true;
+                twin = &kv.second;
                 break;
             }
         }
-        if (!found) {
-            // Blocks with a convection term are not symmetric: the interval comes from the
-            // symmetric part H = (A + A^T) / 2 (Bendixson: Re lambda lies in the spectrum of
-            // D^-1/2 H D^-1/2) and the ellipse's imaginary semi-axis from the spectral radius of
-            // the skew part (|Im lambda| <= rho(D^-1/2 (A - A^T) / 2 D^-1/2)).
-            double *hv = nullptr, *sv2 = nullptr;
-            unsigned nonsym = 0;
-            const int32_t *tpos = transpose_positions();
-            if (tpos) {
-                hv = dev_alloc<double>(P.npadded);
-                sv2 = dev_alloc<double>(P.npadded);
-                unsigned *d_flag = dev_alloc<unsigned>(1);
-                HIPCHK(hipMemsetAsync(d_flag, 0, sizeof(unsigned), st));
-                launch_vals_sym_skew(st, m.vals, tpos, hv, sv2, P.npadded, d_flag);
-                HIPCHK(hipMemcpyAsync(&nonsym, d_flag, sizeof nonsym, hipMemcpyDeviceToHost, st));
-                HIPCHK(hipStreamSynchronize(st));
-                HIPCHK(hipFree(d_flag));
-            }
-            const Spectrum sp = jacobi_spectrum(S_, m_pat_, nonsym ? hv : m.vals, m.dinv, mask_, 400);
-            spectrum_steps_ += sp.steps;
-            if (!(sp.emin > 0.0) || !(sp.emax > sp.emin))
-                fail(KKT_ERR_STATE, "sub-solve matrix is not positive definite: no Chebyshev interval");
-            m.emin = 0.85 * sp.emin;      // Ritz values lie inside the spectrum
-            m.emax = 1.05 * sp.emax;
-            if (nonsym) {
-                int steps = 0;
-                m.eimag = 1.1 * jacobi_skew_radius(S_, m_pat_, sv2, m.dinv, mask_, 40, &steps);
-                spectrum_steps_ += 2 * steps;
-            }
-            if (hv) (void)hipFree(hv);
-            if (sv2) (void)hipFree(sv2);
-        }
     }
+    if (d_.schur_emin > 0) {
+        m.emin = d_.schur_emin;
+        m.emax = d_.schur_emax;
+        m.eimag = d_.schur_eimag > 0 ? d_.schur_eimag : 0.0;
+    } else if (twin) {
+        // Interval from the matrix itself; the first and last levels carry other shifts
+        // (control.py:2241-2327) and get their own, wider, intervals.
+        m.emin = twin->emin;
+        m.emax = twin->emax;
+        m.eimag = twin->eimag;
+    } else {
+        // Blocks with a convection term are not symmetric: the interval comes from the
+        // symmetric part H = (A + A^T) / 2 (Bendixson: Re lambda lies in the spectrum of
+        // D^-1/2 H D^-1/2) and the ellipse's imaginary semi-axis from the spectral radius of
+        // the skew part (|Im lambda| <= rho(D^-1/2 (A - A^T) / 2 D^-1/2)).
+        double *hv = nullptr, *sv2 = nullptr;
+        unsigned nonsym = 0;
+        const int32_t *tpos = transpose_positions();
+        if (tpos) {
+            hv = dev_alloc<double>(P.npadded);
+            sv2 = dev_alloc<double>(P.npadded);
+            unsigned *d_flag = dev_alloc<unsigned>(1);
+            HIPCHK(hipMemsetAsync(d_flag, 0, sizeof(unsigned), st));
+            launch_vals_sym_skew(st, m.vals, tpos, hv, sv2, P.npadded, d_flag);
+            HIPCHK(hipMemcpyAsync(&nonsym, d_flag, sizeof nonsym, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(hipFree(d_flag));
+        }
+        const Spectrum sp = jacobi_spectrum(S_, m_pat_, nonsym ? hv : m.vals, m.dinv, mask_, 400);
+        spectrum_steps_ += sp.steps;
+        if (!(sp.emin > 0.0) || !(sp.emax > sp.emin))
+            fail(KKT_ERR_STATE, "sub-solve matrix is not positive definite: no Chebyshev interval");
+        m.emin = 0.85 * sp.emin;      // Ritz values lie inside the spectrum
+        m.emax = 1.05 * sp.emax;
+        if (nonsym) {
+            int steps = 0;
+            m.eimag = 1.1 * jacobi_skew_radius(S_, m_pat_, sv2, m.dinv, mask_, 40, &steps);
+            spectrum_steps_ += 2 * steps;
+        }
+        if (hv) (void)hipFree(hv);
+        if (sv2) (void)hipFree(sv2);
+        // two-grid form: the sweeps smooth -- they cover the upper part of the spectrum, the
+        // coarse space the rest (emax / 30: measured optimum for 8 sweeps at coarse cells of 8
+        // to 16 mesh widths, scripts/proto_subsolve.py)
+        if (coarse_cycles_ > 0) m.emin = std::max(m.emin, m.emax / 30.0);
+    }
+    if (coarse_cycles_ > 0) m.einv = twin && twin->einv ? twin->einv : coarse_inverse(m.vals);
     mats_[key] = m;
     return m;
 }
@@ -884,6 +1274,7 @@ int SchurPC::resolve_its(const Mat &typical) {
     typical_emin_ = typical.emin;
     typical_emax_ = typical.emax;
     if (d_.schur_its >= 0) return d_.schur_its;
+    if (coarse_cycles_ > 0) return 8;      // smoothing sweeps per cycle
     const double factor = d_.kind == KKT_PC_INSTATIONARY_CN ? 2.6 : 1.6;
     int its = (int)std::ceil(factor * std::sqrt(typical.emax / typical.emin));
     its = std::max(4, std::min(600, its));
@@ -1005,7 +1396,11 @@ void SchurPC::emit_time(double *y, const double *x, int kind, int n, const doubl
 // KSPSolve_Chebyshev (first kind) + PCJACOBI, zero initial guess, exactly `its` steps
 // (options of control.py:1973-1982); its == 0: one Jacobi application (control.py:1984-1991).
 void SchurPC::emit_update_and_solve(Lin upd, const Solve &sv, int its, double emin, double emax,
-                                    double eimag) {
+                                    double eimag, const Mat *mat) {
+    if (coarse_cycles_ > 0 && mat && mat->einv) {
+        emit_coarse_solve(&upd, sv, *mat);
+        return;
+    }
     if (its == 0) {
         upd.y2 = sv.out;        // Jacobi: u = D^-1 b
         upd.dinv = sv.dinv;
@@ -1053,7 +1448,11 @@ void SchurPC::emit_update_and_solve(Lin upd, const Solve &sv, int its, double em
 
 void SchurPC::emit_solves(const std::vector<Solve> &sv, int its, double emin, double emax,
                           double *const P[3], int64_t pstride, bool first_done,
-                          std::vector<TileCoef> *coef_out, double eimag) {
+                          std::vector<TileCoef> *coef_out, double eimag, const Mat *mat) {
+    if (coarse_cycles_ > 0 && mat && mat->einv && sv.size() == 1 && !first_done) {
+        emit_coarse_solve(nullptr, sv[0], *mat);
+        return;
+    }
     const size_t m = sv.size();
     // a single solve on a final right-hand side is a sweep level without update (the first
     // level of a sweep, the sub-solves of the stationary preconditioner)
@@ -1155,9 +1554,9 @@ void SchurPC::build_stationary() {
     emit_lin({Lin{{Term{Dv, u0}}, B_, 1.0, 0.0, -1.0, nullptr, b1}});
     Mat S1 = schur_matrix(Dv, c), S2 = schur_matrix(Dz, c);
     schur_its_ = resolve_its(S1);
-    emit_solves({Solve{S1.vals, S1.dinv, B_, u1}}, schur_its_, S1.emin, S1.emax, P_, nx_, false, nullptr, S1.eimag);
+    emit_solves({Solve{S1.vals, S1.dinv, B_, u1}}, schur_its_, S1.emin, S1.emax, P_, nx_, false, nullptr, S1.eimag, &S1);
     emit_lin({Lin{{Term{m_vals_, u1}}, B_, 1.0}});
-    emit_solves({Solve{S2.vals, S2.dinv, B_, u1}}, schur_its_, S2.emin, S2.emax, P_, nx_, false, nullptr, S2.eimag);
+    emit_solves({Solve{S2.vals, S2.dinv, B_, u1}}, schur_its_, S2.emin, S2.emax, P_, nx_, false, nullptr, S2.eimag, &S2);
 }
 
 // Time sharding: a rank owns blocks [lo, hi).  Everything that is independent
@@ -1234,9 +1633,9 @@ void SchurPC::build_BE() {
                 emit_update_and_solve(Lin{{Term{block_vals(KKT_Q10, i, i - 1),
                                                 i - 1 >= lo ? blk(u1, i - 1) : h_u1_}},
                                           blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i), nullptr},
-                                      sv, schur_its_, F.emin, F.emax, F.eimag);
+                                      sv, schur_its_, F.emin, F.emax, F.eimag, &F);
             else
-                emit_solves({sv}, schur_its_, F.emin, F.emax, P_, nx_, false, nullptr, F.eimag);
+                emit_solves({sv}, schur_its_, F.emin, F.emax, P_, nx_, false, nullptr, F.eimag, &F);
         }
     };
     if (lanes) {
@@ -1272,9 +1671,9 @@ void SchurPC::build_BE() {
             emit_update_and_solve(Lin{{Term{block_vals(KKT_Q01, i, i + 1),
                                             i + 1 < hi ? blk(u1, i + 1) : h_u1_}},
                                       blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i), nullptr},
-                                  sv, schur_its_, G.emin, G.emax, G.eimag);
+                                  sv, schur_its_, G.emin, G.emax, G.eimag, &G);
         else
-            emit_solves({sv}, schur_its_, G.emin, G.emax, P_, nx_, false, nullptr, G.eimag);
+            emit_solves({sv}, schur_its_, G.emin, G.emax, P_, nx_, false, nullptr, G.eimag, &G);
     }
     if (dn >= 0) emit_comm(blk(u1, lo), dn, nullptr, -1);
 }
@@ -1344,9 +1743,9 @@ void SchurPC::build_CN() {
             emit_update_and_solve(Lin{{Term{block_vals(KKT_Q10, i, i - 1), prev},
                                        Term{cM.vals, prev}},
                                       blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i), nullptr},
-                                  sv, schur_its_, F.emin, F.emax, F.eimag);
+                                  sv, schur_its_, F.emin, F.emax, F.eimag, &F);
         } else {
-            emit_solves({sv}, schur_its_, F.emin, F.emax, P_, nx_, false, nullptr, F.eimag);
+            emit_solves({sv}, schur_its_, F.emin, F.emax, P_, nx_, false, nullptr, F.eimag, &F);
         }
     }
     if (up >= 0) emit_comm(blk(u1, hi - 1), up, nullptr, -1);
@@ -1367,9 +1766,9 @@ void SchurPC::build_CN() {
             Mat H = schur_matrix(block_vals(KKT_Q01, i, i + 1), c);
             emit_update_and_solve(Lin{{Term{H.vals, i + 1 < hi ? blk(u1, i + 1) : h_u1_}},
                                       blk(B_, i), -1.0, 1.0, 0.0, blk(B_, i), nullptr},
-                                  sv, schur_its_, G.emin, G.emax, G.eimag);
+                                  sv, schur_its_, G.emin, G.emax, G.eimag, &G);
         } else {
-            emit_solves({sv}, schur_its_, G.emin, G.emax, P_, nx_, false, nullptr, G.eimag);
+            emit_solves({sv}, schur_its_, G.emin, G.emax, P_, nx_, false, nullptr, G.eimag, &G);
         }
     }
     if (dn >= 0) emit_comm(blk(u1, lo), dn, nullptr, -1);
@@ -1421,6 +1820,9 @@ void SchurPC::replay(size_t first, size_t last) {
             case PcStep::COPY:
                 launch_copy(st, s.y, s.x, s.nx);
                 break;
+            case PcStep::COARSE:
+                launch_coarse_correction(st, coarse_, s.einv, s.cr, s.x, s.y, s.nx);
+                break;
             case PcStep::PROG: {
                 const Pattern &P = S_.patterns[m_pat_];
                 if (s.gmode == 2)
@@ -1437,6 +1839,10 @@ void SchurPC::replay(size_t first, size_t last) {
             case PcStep::TILE: {
                 const TilePlan &tp = tile_plan_;
                 TileArgs a{};
+                a.coarse = s.coarse ? d_tile_coarse_ : nullptr;
+                a.einv = s.d_einv;
+                a.cycles = s.coarse ? coarse_cycles_ : 0;
+                a.cepoch0 = s.cepoch0;
                 a.nlevels = s.nlevels;
                 a.its = s.its;
                 a.depth = tp.depth;
@@ -1467,7 +1873,8 @@ void SchurPC::replay(size_t first, size_t last) {
                 }
                 try {
                     launch_tile_sweep(st, a, s.d_levels, tp.d_n, tp.d_grow, tp.d_lcol, tp.d_gpos,
-                                      mask_, tp.ntiles, tp.threads, words);
+                                      mask_, tp.ntiles, tp.threads, words,
+                                      s.coarse ? &h_tile_coarse_ : nullptr);
                 } catch (const TileLaunchError &e) {
                     fail(KKT_ERR_HIP, e.msg);
                 }

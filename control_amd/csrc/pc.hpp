@@ -27,7 +27,9 @@ double jacobi_skew_radius(System &S, int pattern, const double *skew_vals, const
                           const uint8_t *rowmask, int max_steps, int *steps_out);
 
 struct PcStep {
-    enum Kind { ROWS, TIME, COPY, COMM, PROG, TILE, EV_RECORD, EV_WAIT } kind;
+    enum Kind { ROWS, TIME, COPY, COMM, PROG, TILE, EV_RECORD, EV_WAIT, COARSE } kind;
+    const double *einv = nullptr;   // COARSE: y = (x or 0) + P E^-1 P^T cr
+    const double *cr = nullptr;     // COARSE: the residual that is restricted
     int lane = 0;                   // 0: the system's stream; 1: the side stream
     int ev = -1;                    // EV_RECORD / EV_WAIT: event index
     RowLaunch rows;                 // ROWS
@@ -46,6 +48,9 @@ struct PcStep {
     uint32_t epoch0 = 0;            // TILE: first hand-off tag of this launch minus one
     bool fused = true;              // TILE: kernel variant with the level update
     bool clear = false;             // TILE: zero the granule buffers first
+    bool coarse = false;            // TILE: two-grid levels
+    const double **d_einv = nullptr;   // TILE, coarse: per level (P^T A P)^-1
+    uint32_t cepoch0 = 0;           // TILE, coarse: first coarse-exchange tag of this launch minus one
 };
 
 // A device-resident pc_fn: reads the nullspace-corrected right-hand side from in(), leaves
@@ -122,11 +127,25 @@ class SchurPC : public PcBase {
         double *dinv;
         double emin = 0.0, emax = 0.0;   // Chebyshev interval of this matrix (given or estimated)
         double eimag = 0.0;              // > 0: imaginary semi-axis of the spectrum's ellipse
+        double *einv = nullptr;          // two-grid form: (P^T A P)^-1, nc x nc row-major (shared
+                                         // by matrices with equal values: freed through einv_owned_)
     };
     int schur_its_ = 0;                  // degree of the sub-solves (given or derived)
     double typical_emin_ = 0.0, typical_emax_ = 0.0;
     int resolve_its(const Mat &typical);
     int64_t spectrum_steps_ = 0;         // Lanczos steps spent on estimates (reported when verbose)
+    // two-grid form of the sub-solves (kkt_pc_desc.coarse_*)
+    int coarse_cycles_ = 0;
+    std::vector<int32_t> p_indptr_, p_indices_;
+    std::vector<double> p_values_;
+    std::vector<int32_t> pt_indptr_, pt_indices_;      // P^T (host copies: tile plan)
+    std::vector<double> pt_values_;
+    CoarseDev coarse_;
+    std::vector<double *> einv_owned_;
+    double *R_ = nullptr;                // residual of a cycle (one block)
+    void build_coarse();
+    double *coarse_inverse(const double *vals);       // (P^T A P)^-1 on the device
+    void emit_coarse(const double *r, const double *x_in, double *x_out, const double *einv);
     std::map<std::pair<const double *, uint64_t>, Mat> mats_;
     double *h_u0_ = nullptr, *h_u1_ = nullptr, *h_t_ = nullptr;   // one-block halos
     std::vector<PcStep> steps_;
@@ -169,11 +188,19 @@ class SchurPC : public PcBase {
         int its = 0;
         bool eligible = false;
         const double *b_after = nullptr;   // the right-hand side after the update (B_i)
+        bool coarse = false;               // two-grid level: coef holds sweeps 1 .. its
+        const double *einv = nullptr;      // its (P^T A P)^-1
     };
     std::vector<SweepLevel> sweep_levels_;
     TilePlan tile_plan_;
     bool tile_tried_ = false, tile_ok_ = false;
     size_t tile_lds_checked_ = 0;       // dynamic LDS bytes residency was checked for
+    // coarse corrections inside the tile program (kernels.hpp, TileCoarseDev)
+    TileCoarseDev h_tile_coarse_{};     // host copy (device pointers inside)
+    TileCoarseDev *d_tile_coarse_ = nullptr;
+    bool tile_coarse_ok_ = false;
+    uint32_t tile_cepoch_cursor_ = 0;
+    bool build_tile_coarse();
     unsigned long long *d_tg_[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<void *> tile_owned_;    // coefficient tables of the current program
     uint32_t tile_epoch_cursor_ = 0;    // hand-off tags handed out to the launches of one application
@@ -218,11 +245,13 @@ class SchurPC : public PcBase {
     };
     void emit_solves(const std::vector<Solve> &sv, int its, double emin, double emax,
                      double *const P[3], int64_t pstride, bool first_done = false,
-                     std::vector<TileCoef> *coef_out = nullptr, double eimag = 0.0);
+                     std::vector<TileCoef> *coef_out = nullptr, double eimag = 0.0,
+                     const Mat *mat = nullptr);
     // the sweep step "b -= A u_prev (masked), then solve": the update and the first
     // Chebyshev step share one launch
     void emit_update_and_solve(Lin upd, const Solve &sv, int its, double emin, double emax,
-                               double eimag = 0.0);
+                               double eimag = 0.0, const Mat *mat = nullptr);
+    void emit_coarse_solve(const Lin *upd, const Solve &sv, const Mat &F);
     // position of the transposed entry of every stored entry of the preconditioner's sparsity
     // structure (device array, built on first use; null when the structure is not symmetric)
     const int32_t *transpose_positions();

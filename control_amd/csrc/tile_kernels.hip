@@ -86,7 +86,9 @@ __device__ __forceinline__ unsigned opaque(unsigned x) {
 }
 
 // HPT_: ring-entry slots per thread of a hand-off (RPT + 1 unless the variant is short of registers)
-template <int W, int RPT, int TMAX, bool UPD, int HPT_ = RPT + 1>
+// COARSE: levels are cycles of [Galerkin coarse correction, `its` smoothing sweeps] (two-grid form
+// of the sub-solves); the plain variants compile none of it.
+template <int W, int RPT, int TMAX, bool UPD, int HPT_ = RPT + 1, bool COARSE = false>
 __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     const TileArgs A, const TileLevel *__restrict__ levels, const int32_t *__restrict__ n_all,
     const int32_t *__restrict__ grow_all, const uint16_t *__restrict__ lcol_all,
@@ -213,7 +215,68 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     // step coefficients live in LDS behind the two iterates: a global load inside the step loop
     // would be drained by every workgroup barrier (vmcnt(0)), a round trip per step
     double *scoef = X + 2 * (size_t)nkp;
-    double *dump = scoef + 3 * (size_t)(its > 1 ? its - 1 : 1);
+    // (coarse levels: the table also holds the first sweep after a correction, `its` entries)
+    double *dump = scoef + 3 * (size_t)(COARSE ? (its > 0 ? its : 1) : (its > 1 ? its - 1 : 1));
+    // coarse corrections: every tile's partial sums, the coarse residual, this tile's corrections
+    double *SL = dump + 1, *RC = nullptr, *EC = nullptr;
+    int c_nc = 0, c_jmax = 0, c_n0max = 0, c_nslots = 0, c_nj = 0, c_slot0 = 0;
+    unsigned cepoch = A.cepoch0;
+    if constexpr (COARSE) {
+        const TileCoarseDev *cd = A.coarse;
+        c_nc = cd->nc;
+        c_jmax = cd->jmax;
+        c_n0max = cd->n0max;
+        c_nslots = cd->nslots;
+        c_nj = cd->nj[tile];
+        c_slot0 = cd->slot0[tile];
+        RC = SL + c_nslots;
+        EC = RC + c_nc;
+    }
+    // ... and what never changes between corrections, copied into LDS once (read from memory per
+    // correction it was a chain of eight dependent round trips, ~25 us per level): the tile's
+    // restriction lists and prolongation entries, the slot -> coarse function map
+    double *RWc = nullptr, *PWc = nullptr;
+    int *CSLc = nullptr, *CIPc = nullptr, *RIPc = nullptr, *JGc = nullptr;
+    uint16_t *RROWc = nullptr, *PKc = nullptr;
+    int pe0[RPT], pe1[RPT];
+    if constexpr (COARSE) {
+        const TileCoarseDev *cd = A.coarse;
+        const int nrm = cd->nr_max;
+        RWc = EC + c_jmax;
+        PWc = RWc + nrm;
+        CSLc = reinterpret_cast<int *>(PWc + nrm);
+        CIPc = CSLc + c_nslots;
+        RIPc = CIPc + (c_nc + 1);
+        JGc = RIPc + (c_jmax + 1);
+        RROWc = reinterpret_cast<uint16_t *>(JGc + c_jmax);
+        PKc = RROWc + nrm;
+        const gci_p rip = (gci_p)cd->r_ip + (size_t)tile * c_jmax;
+        const gci_p pip = (gci_p)cd->p_ip + (size_t)tile * c_n0max;
+        const int re0 = rip[0], re1 = rip[c_nj], pq0 = pip[0], pq1 = pip[nt[0]];
+        const gcu16_p rrow = (gcu16_p)cd->r_row, pk = (gcu16_p)cd->p_k;
+        const gcd_p rw = (gcd_p)cd->r_w, pw = (gcd_p)cd->p_w;
+        for (int i = tid; i < re1 - re0; i += T) {
+            RWc[i] = rw[re0 + i];
+            RROWc[i] = rrow[re0 + i];
+        }
+        for (int i = tid; i < pq1 - pq0; i += T) {
+            PWc[i] = pw[pq0 + i];
+            PKc[i] = pk[pq0 + i];
+        }
+        const gci_p cslot = (gci_p)cd->c_slot, cip = (gci_p)cd->c_ip;
+        for (int i = tid; i < c_nslots; i += T) CSLc[i] = cslot[i];
+        for (int i = tid; i <= c_nc; i += T) CIPc[i] = cip[i];
+        const gci_p jg = (gci_p)cd->jglob + (size_t)tile * c_jmax;
+        for (int i = tid; i <= c_nj; i += T) RIPc[i] = rip[i] - re0;
+        for (int i = tid; i < c_nj; i += T) JGc[i] = jg[i];
+#pragma unroll
+        for (int sl = 0; sl < RPT; ++sl) {
+            const int r = sl * T + tid;
+            pe0[sl] = r < nt[0] ? pip[r] - pq0 : 0;
+            pe1[sl] = r < nt[0] ? pip[r + 1] - pq0 : 0;
+        }
+        __syncthreads();
+    }
     const void *coef_key = nullptr;
     int cur = 0;             // X + cur * nkp: the newest iterate; the other half: the one before
     unsigned epoch = A.epoch0;   // tags never repeat between the launches of one application
@@ -429,8 +492,10 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     // Variants without that room (1 024 threads: 128 registers) still keep the values of the next
     // update's matrix out of the level's first step: they are requested together with the next
     // matrix in front of the hand-off that ends the level (PRE_U).
-    constexpr bool PRE = UPD && W * RPT <= 14 && TMAX <= 512;
-    constexpr bool PRE_U = UPD && !PRE && W * RPT <= 7;
+    // (two-grid levels are short -- a correction and a handful of sweeps -- and their exchanges
+    // need the registers: no operands of the next level are held across them)
+    constexpr bool PRE = UPD && !COARSE && W * RPT <= 14 && TMAX <= 512;
+    constexpr bool PRE_U = UPD && !COARSE && !PRE && W * RPT <= 7;
     constexpr int PR = PRE ? RPT : 1, PW = PRE ? W : 1;
     constexpr int UR = (PRE || PRE_U) ? RPT : 1, UW = (PRE || PRE_U) ? W : 1;
     double vn[PR][PW], un[UR][UW], dn[PR], bn[PR];
@@ -504,7 +569,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
             coef_key = (const void *)L.coef;
             const gcd_p cp = (gcd_p)(const double *)L.coef;
             __syncthreads();   // nobody still reads the old table
-            for (int i = tid; i < 3 * (its - 1); i += T) scoef[i] = cp[i];
+            for (int i = tid; i < 3 * (COARSE ? its : its - 1); i += T) scoef[i] = cp[i];
             // (the barrier after the first step of the level orders these writes before their use)
         }
         // Everything loaded for the level is pinned in registers here: a value whose load is
@@ -655,47 +720,22 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
             asm volatile("" : "+v"(b[sl]));
         }
         lap(2, 1);
-        // ---- Chebyshev steps 2 .. its, `depth` of them per hand-off
-        // (row count and coefficients of a step are read from LDS one step ahead: they land with
-        // the barrier's own wait instead of in front of the step's gathers)
-        int nv_next = sn[(cr == 0 ? depth : cr) - 1];
-        double cn1 = scoef[0], cn2 = scoef[1], cn3 = scoef[2];
-        bool early_done = false;   // the step before published the own rows already
-        for (int s = 2; s <= its; ++s) {
-            if (cr == 0) {
-                handoff(s >= 3, early_done);
-                early_done = false;
-                cr = depth;
-                // the last round of the level: the next level's operands travel under it
-                if (PRE && has_next && its - s < depth) prefetch_level(Nf);
-            }
-            const int nv = nv_next;
-            const double cf1 = cn1, cf2 = cn2, cf3 = cn3;
-            const bool last = s == its;
-            const double q1 = last ? post1 : 1.0, q2 = last ? post2 : 1.0;
-            const bool has_old = s >= 3;
-            double *Xc = X + cur * nkp, *Xo = X + (cur ^ 1) * nkp;
-            // a hand-off follows this step inside the level
-            // (wide rows only -- on narrow rows at depth 5-7 the stores in the step cost more
-            // than the hand-off gains: 0.45 -> 0.51 us per step, 3.58 -> 3.37 us per hand-off)
-            const bool pub_next = PACK && cr == 1 && s < its;
-            const bool pub_drop =
-                tile == 0 && A.debug_drop > 0 && (int)(epoch + 1 - A.epoch0) == A.debug_drop;
-            early_done = pub_next;
-            const __amdgpu_buffer_rsrc_t rn_next = __builtin_amdgcn_make_buffer_rsrc(
-                (void *)A.gnew[(epoch + 1) & 1], 0, (int)A.granule_bytes, 0x00020000);
-            if constexpr (PACK) {
+        if constexpr (COARSE) {
+            // ---- two-grid level: cycles of [coarse correction of the iterate; `its` sweeps]
+            // One SpMV step of this path on the rows [0, nv): mode 0 the Chebyshev update
+            // p+ = c1 p- + c2 p + c3 D^-1 (b - A p) into the older buffer, mode 1 the residual
+            // b - A p.  The fma chain of a row is the plain kernels' (slot order).
+            auto cstep = [&](const int mode, const int nv, const double cf1, const double cf2,
+                             const double cf3, const bool has_old, const double q1,
+                             const double q2) {
+                double *Xc = X + cur * nkp, *Xo = X + (cur ^ 1) * nkp;
 #pragma unroll
                 for (int sl = 0; sl < RPT; ++sl) {
-                    // wave-uniform: none of this wave's 64 rows of the slot is live on the
-                    // shrunken region
-                    if (sl * T + (tid & ~63) >= nv) continue;
+                    if (sl * T + (tid & ~63) >= nv) continue;      // wave-uniform
                     const int r = sl * T + tid;
                     double acc = 0.0;
 #pragma unroll
                     for (int k0 = 0; k0 < W; k0 += CH) {
-                        // (wide rows: a bounded number of gathers in flight, or the registers of
-                        // the matrix values spill)
                         double xv[CH];
 #pragma unroll
                         for (int k = 0; k < CH; ++k)
@@ -703,88 +743,294 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
 #pragma unroll
                         for (int k = 0; k < CH; ++k)
                             if (k0 + k < W) acc = __builtin_fma(v[sl][k0 + k], xv[k], acc);
-                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (PACK) __builtin_amdgcn_sched_barrier(0);
                     }
                     if (r < nv) {
-                        const double e0 = Xo[r], e1 = Xc[r];
                         double out = 0.0;
                         if (!msk[sl]) {
-                            double t = has_old ? cf1 * e0 : 0.0;
-                            t += cf2 * e1;
-                            t += cf3 * (dinv[sl] * (b[sl] - acc));
-                            out = q2 * (q1 * t);
+                            if (mode == 0) {
+                                const double e0 = Xo[r], e1 = Xc[r];
+                                double t = has_old ? cf1 * e0 : 0.0;
+                                t += cf2 * e1;
+                                t += cf3 * (dinv[sl] * (b[sl] - acc));
+                                out = q2 * (q1 * t);
+                            } else {
+                                out = b[sl] - acc;
+                            }
                         }
                         Xo[r] = out;
-                        // last step of a round: the own rows leave at once, with the number of
-                        // the hand-off that follows (the rest of the step runs under their flight)
-                        if (pub_next && !pub_drop && r < n0)
-                            publish(rn_next, gr[sl], out, epoch + 1);
                     }
                 }
-            } else {
-                // Narrow rows: a step is a latency chain (gather, W dependent fmas, epilogue,
-                // store, barrier), not a throughput problem -- the slots of a thread run side by
-                // side: every gather of every live slot is issued before the first fma.  Live
-                // slots are a prefix (rows of a slot lie behind those of the one before); a wave
-                // none of whose 64 rows of a slot is live on the shrunken region skips the slot.
-                int nl = 0;
-                long long keep[RPT];
+            };
+            const TileCoarseDev *cd = A.coarse;
+            const gcd_p einv = (gcd_p)A.einv[lev];
+            const int wave = tid >> 6, lane = tid & 63, nwaves = T >> 6;
+            for (int cyc = 0; cyc < A.cycles; ++cyc) {
+                // ---- residual of the current iterate on the own rows, into the older buffer
+                if (cyc == 0) {
+                    double *Xo = X + (cur ^ 1) * nkp;
 #pragma unroll
-                for (int sl = 0; sl < RPT; ++sl) {
-                    if (sl * T + (tid & ~63) < nv) nl = sl + 1;
-                    keep[sl] = msk[sl] ? 0ll : -1ll;
-                    asm volatile("" : "+v"(keep[sl]));
+                    for (int sl = 0; sl < RPT; ++sl) {
+                        const int r = sl * T + tid;
+                        if (r < n0) Xo[r] = b[sl];          // zero guess: r = b
+                    }
+                } else {
+                    if (cr == 0) {                          // the first ring must be valid
+                        handoff(false);
+                        cr = depth;
+                    }
+                    cstep(1, n0, 0.0, 0.0, 0.0, false, 1.0, 1.0);
                 }
-                auto body = [&](auto NLc) {
-                    constexpr int NL = decltype(NLc)::value;
-                    double xv[NL][W], e0[NL], e1[NL], acc[NL];
+                lds_barrier();
+                // ---- restriction: partial sums over the own rows for the coarse functions they
+                // touch, a wave per function, lanes stride its list, fixed butterfly
+                ++cepoch;
+                {
+                    const double *Rb = X + (cur ^ 1) * nkp;
+                    const __amdgpu_buffer_rsrc_t rc_ = __builtin_amdgcn_make_buffer_rsrc(
+                        (void *)cd->cg[cepoch & 1], 0, (int)cd->cg_bytes, 0x00020000);
+                    for (int k = wave; k < c_nj; k += nwaves) {
+                        const int e0 = RIPc[k], e1 = RIPc[k + 1];
+                        double a = 0.0;
+                        for (int e = e0 + lane; e < e1; e += 64)
+                            a = __builtin_fma(RWc[e], Rb[RROWc[e]], a);
 #pragma unroll
-                    for (int sl = 0; sl < NL; ++sl) {
-#pragma unroll
-                        for (int k = 0; k < W; ++k) xv[sl][k] = Xc[KKT_COL(sl, k)];
-                        const int r = sl * T + tid;
-                        e0[sl] = Xo[r];
-                        e1[sl] = Xc[r];
-                        acc[sl] = 0.0;
+                        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+                        if (lane == 0) publish(rc_, c_slot0 + k, a, cepoch);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    // ---- every tile's partial sums ("the data is the flag"), then the coarse
+                    // residual: contributions of a function summed in slot (= tile) order
+                    // (4 slots per thread in flight; more slots than 4 T: further rounds, whose
+                    // granules have mostly landed by then.  8 in flight made the compiler spill
+                    // ~200 registers in the 512-thread variants.)
+                    constexpr int CSL = 4;
+                    for (int i = 0; i < A.poll_delay; ++i) __builtin_amdgcn_s_sleep(1);
+                    for (int base = 0; base < c_nslots; base += CSL * T) {
+                        u32x4 g[CSL];
 #pragma unroll
-                    for (int k = 0; k < W; ++k)
+                        for (int q = 0; q < CSL; ++q) g[q] = u32x4{0u, 0u, 0u, 0u};
+                        unsigned spins = 0;
+                        while (true) {
+                            asm volatile("" ::: "memory");
+                            bool ok = true;
 #pragma unroll
-                        for (int sl = 0; sl < NL; ++sl)
-                            acc[sl] = __builtin_fma(v[sl][k], xv[sl][k], acc[sl]);
+                            for (int q = 0; q < CSL; ++q) {
+                                const int sidx = base + q * T + tid;
+                                if (sidx < c_nslots && (g[q].y != cepoch || g[q].w != cepoch))
+                                    g[q] = __builtin_amdgcn_raw_buffer_load_b128(rc_, sidx * 16, 0, 16);
+                            }
 #pragma unroll
-                    for (int sl = 0; sl < NL; ++sl) {
-                        const int r = sl * T + tid;
-                        // (boundary rows: a bit mask, not a branch or a select the compiler
-                        // turns into one -- a branch per slot would put the chains of the slots
-                        // one behind the other again)
-                        double t = has_old ? cf1 * e0[sl] : 0.0;
-                        t += cf2 * e1[sl];
-                        t += cf3 * (dinv[sl] * (b[sl] - acc[sl]));
-                        const double out = __longlong_as_double(
-                            __double_as_longlong(q2 * (q1 * t)) & keep[sl]);
-                        // rows behind the live region store into a dump slot: an unconditional
-                        // store keeps the compiler from sinking the chain into a branch per slot
-                        *(r < nv ? Xo + r : dump) = out;
+                            for (int q = 0; q < CSL; ++q) {
+                                const int sidx = base + q * T + tid;
+                                if (sidx < c_nslots) ok &= g[q].y == cepoch && g[q].w == cepoch;
+                            }
+                            if (ok || dead) break;
+                            if (++spins >= TILE_SPIN_LIMIT) {
+                                dead = true;
+                                sdead = 1;
+                                atomicOr(A.err, 4u);
+                                if (atomicCAS(A.err + 1, 0u, 1u) == 0u) {
+                                    A.err[8] = (unsigned)tile;
+                                    A.err[9] = cepoch;
+                                    A.err[10] = 0xffffu;            // a coarse exchange
+                                    A.err[11] = (unsigned)(base + tid);
+                                    A.err[12] = g[0].y;
+                                    A.err[13] = g[0].w;
+                                    A.err[16] = 2u;
+                                }
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+#pragma unroll
+                        for (int q = 0; q < CSL; ++q) {
+                            const int sidx = base + q * T + tid;
+                            if (sidx < c_nslots)
+                                SL[sidx] = __longlong_as_double((long long)(
+                                    (unsigned long long)g[q].x | ((unsigned long long)g[q].z << 32)));
+                        }
                     }
-                };
-                if (nl == 1) body(std::integral_constant<int, 1>{});
-                if constexpr (RPT >= 2)
-                    if (nl == 2) body(std::integral_constant<int, 2>{});
-                if constexpr (RPT >= 3)
-                    if (nl == 3) body(std::integral_constant<int, 3>{});
+                    lds_barrier();
+                    dead = sdead != 0;
+                    for (int j = tid; j < c_nc; j += T) {
+                        double a = 0.0;
+                        for (int q = CIPc[j]; q < CIPc[j + 1]; ++q) a += SL[CSLc[q]];
+                        RC[j] = a;
+                    }
+                    lds_barrier();
+                    // ---- this tile's rows of (P^T A P)^-1, a wave per coarse function
+                    for (int k = wave; k < c_nj; k += nwaves) {
+                        const gcd_p row = einv + (size_t)JGc[k] * c_nc;
+                        double a = 0.0;
+                        for (int q = lane; q < c_nc; q += 64) a = __builtin_fma(row[q], RC[q], a);
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+                        if (lane == 0) EC[k] = a;
+                    }
+                    lds_barrier();
+                    // ---- prolongation onto the own rows of the current iterate
+                    double *Xc = X + cur * nkp;
+#pragma unroll
+                    for (int sl = 0; sl < RPT; ++sl) {
+                        const int r = sl * T + tid;
+                        if (r < n0) {
+                            double a = 0.0;
+                            for (int e = pe0[sl]; e < pe1[sl]; ++e)
+                                a = __builtin_fma(PWc[e], EC[PKc[e]], a);
+                            Xc[r] = cyc == 0 ? a : Xc[r] + a;
+                        }
+                    }
+                }
+                // (the barrier inside the hand-off orders these stores before anyone's gathers)
+                lds_barrier();
+                handoff(false);
+                cr = depth;
+                // ---- smoothing sweeps from the corrected iterate
+                for (int s = 1; s <= its; ++s) {
+                    if (cr == 0) {
+                        handoff(s >= 2);
+                        cr = depth;
+                    }
+                    const bool last = cyc + 1 == A.cycles && s == its;
+                    cstep(0, sn[cr - 1], scoef[3 * (s - 1)], scoef[3 * (s - 1) + 1],
+                          scoef[3 * (s - 1) + 2], s >= 2, last ? post1 : 1.0, last ? post2 : 1.0);
+                    lds_barrier();
+                    cur ^= 1;
+                    --cr;
+                }
             }
-            if (s < its) {
-                const int crn = cr - 1 == 0 ? depth : cr - 1;
-                nv_next = sn[crn - 1];
-                cn1 = scoef[3 * (s - 1)];
-                cn2 = scoef[3 * (s - 1) + 1];
-                cn3 = scoef[3 * (s - 1) + 2];
+        } else {
+            // ---- Chebyshev steps 2 .. its, `depth` of them per hand-off
+            // (row count and coefficients of a step are read from LDS one step ahead: they land with
+            // the barrier's own wait instead of in front of the step's gathers)
+            int nv_next = sn[(cr == 0 ? depth : cr) - 1];
+            double cn1 = scoef[0], cn2 = scoef[1], cn3 = scoef[2];
+            bool early_done = false;   // the step before published the own rows already
+            for (int s = 2; s <= its; ++s) {
+                if (cr == 0) {
+                    handoff(s >= 3, early_done);
+                    early_done = false;
+                    cr = depth;
+                    // the last round of the level: the next level's operands travel under it
+                    if (PRE && has_next && its - s < depth) prefetch_level(Nf);
+                }
+                const int nv = nv_next;
+                const double cf1 = cn1, cf2 = cn2, cf3 = cn3;
+                const bool last = s == its;
+                const double q1 = last ? post1 : 1.0, q2 = last ? post2 : 1.0;
+                const bool has_old = s >= 3;
+                double *Xc = X + cur * nkp, *Xo = X + (cur ^ 1) * nkp;
+                // a hand-off follows this step inside the level
+                // (wide rows only -- on narrow rows at depth 5-7 the stores in the step cost more
+                // than the hand-off gains: 0.45 -> 0.51 us per step, 3.58 -> 3.37 us per hand-off)
+                const bool pub_next = PACK && cr == 1 && s < its;
+                const bool pub_drop =
+                    tile == 0 && A.debug_drop > 0 && (int)(epoch + 1 - A.epoch0) == A.debug_drop;
+                early_done = pub_next;
+                const __amdgpu_buffer_rsrc_t rn_next = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)A.gnew[(epoch + 1) & 1], 0, (int)A.granule_bytes, 0x00020000);
+                if constexpr (PACK) {
+    #pragma unroll
+                    for (int sl = 0; sl < RPT; ++sl) {
+                        // wave-uniform: none of this wave's 64 rows of the slot is live on the
+                        // shrunken region
+                        if (sl * T + (tid & ~63) >= nv) continue;
+                        const int r = sl * T + tid;
+                        double acc = 0.0;
+    #pragma unroll
+                        for (int k0 = 0; k0 < W; k0 += CH) {
+                            // (wide rows: a bounded number of gathers in flight, or the registers of
+                            // the matrix values spill)
+                            double xv[CH];
+    #pragma unroll
+                            for (int k = 0; k < CH; ++k)
+                                if (k0 + k < W) xv[k] = Xc[KKT_COL(sl, k0 + k)];
+    #pragma unroll
+                            for (int k = 0; k < CH; ++k)
+                                if (k0 + k < W) acc = __builtin_fma(v[sl][k0 + k], xv[k], acc);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (r < nv) {
+                            const double e0 = Xo[r], e1 = Xc[r];
+                            double out = 0.0;
+                            if (!msk[sl]) {
+                                double t = has_old ? cf1 * e0 : 0.0;
+                                t += cf2 * e1;
+                                t += cf3 * (dinv[sl] * (b[sl] - acc));
+                                out = q2 * (q1 * t);
+                            }
+                            Xo[r] = out;
+                            // last step of a round: the own rows leave at once, with the number of
+                            // the hand-off that follows (the rest of the step runs under their flight)
+                            if (pub_next && !pub_drop && r < n0)
+                                publish(rn_next, gr[sl], out, epoch + 1);
+                        }
+                    }
+                } else {
+                    // Narrow rows: a step is a latency chain (gather, W dependent fmas, epilogue,
+                    // store, barrier), not a throughput problem -- the slots of a thread run side by
+                    // side: every gather of every live slot is issued before the first fma.  Live
+                    // slots are a prefix (rows of a slot lie behind those of the one before); a wave
+                    // none of whose 64 rows of a slot is live on the shrunken region skips the slot.
+                    int nl = 0;
+                    long long keep[RPT];
+    #pragma unroll
+                    for (int sl = 0; sl < RPT; ++sl) {
+                        if (sl * T + (tid & ~63) < nv) nl = sl + 1;
+                        keep[sl] = msk[sl] ? 0ll : -1ll;
+                        asm volatile("" : "+v"(keep[sl]));
+                    }
+                    auto body = [&](auto NLc) {
+                        constexpr int NL = decltype(NLc)::value;
+                        double xv[NL][W], e0[NL], e1[NL], acc[NL];
+    #pragma unroll
+                        for (int sl = 0; sl < NL; ++sl) {
+    #pragma unroll
+                            for (int k = 0; k < W; ++k) xv[sl][k] = Xc[KKT_COL(sl, k)];
+                            const int r = sl * T + tid;
+                            e0[sl] = Xo[r];
+                            e1[sl] = Xc[r];
+                            acc[sl] = 0.0;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                        for (int k = 0; k < W; ++k)
+    #pragma unroll
+                            for (int sl = 0; sl < NL; ++sl)
+                                acc[sl] = __builtin_fma(v[sl][k], xv[sl][k], acc[sl]);
+    #pragma unroll
+                        for (int sl = 0; sl < NL; ++sl) {
+                            const int r = sl * T + tid;
+                            // (boundary rows: a bit mask, not a branch or a select the compiler
+                            // turns into one -- a branch per slot would put the chains of the slots
+                            // one behind the other again)
+                            double t = has_old ? cf1 * e0[sl] : 0.0;
+                            t += cf2 * e1[sl];
+                            t += cf3 * (dinv[sl] * (b[sl] - acc[sl]));
+                            const double out = __longlong_as_double(
+                                __double_as_longlong(q2 * (q1 * t)) & keep[sl]);
+                            // rows behind the live region store into a dump slot: an unconditional
+                            // store keeps the compiler from sinking the chain into a branch per slot
+                            *(r < nv ? Xo + r : dump) = out;
+                        }
+                    };
+                    if (nl == 1) body(std::integral_constant<int, 1>{});
+                    if constexpr (RPT >= 2)
+                        if (nl == 2) body(std::integral_constant<int, 2>{});
+                    if constexpr (RPT >= 3)
+                        if (nl == 3) body(std::integral_constant<int, 3>{});
+                }
+                if (s < its) {
+                    const int crn = cr - 1 == 0 ? depth : cr - 1;
+                    nv_next = sn[crn - 1];
+                    cn1 = scoef[3 * (s - 1)];
+                    cn2 = scoef[3 * (s - 1) + 1];
+                    cn3 = scoef[3 * (s - 1) + 2];
+                }
+                lds_barrier();
+                cur ^= 1;
+                --cr;
             }
-            lds_barrier();
-            cur ^= 1;
-            --cr;
         }
         lap(1, (unsigned long long)(its - 1));
         // ---- result of the level: own rows to memory; the next level's update multiplies it
@@ -829,7 +1075,10 @@ typedef void (*tile_fn)(const TileArgs, const TileLevel *, const int32_t *, cons
 // (2-D P1) run 512 threads with up to three row slots or 1 024 with one, level update fused.
 // Wide rows (3-D P1: 15 entries, 30 registers of matrix values per row slot) run 512 threads with
 // two slots in the variant without the fused update (244 registers; with it 256 + 78 spilled).
-static tile_fn pick_tile(int W, int rpt, int threads, bool fused = true, int hslots = 0) {
+static tile_fn pick_tile_coarse(int W, int rpt, int threads, int hslots);
+static tile_fn pick_tile(int W, int rpt, int threads, bool fused = true, int hslots = 0,
+                         bool coarse = false) {
+    if (coarse) return fused ? pick_tile_coarse(W, rpt, threads, hslots) : nullptr;
     if (hslots <= 0) hslots = 1;
 #define KKT_T(w)                                                           \
     if (W == w) {                                                          \
@@ -863,11 +1112,50 @@ static tile_fn pick_tile(int W, int rpt, int threads, bool fused = true, int hsl
     return nullptr;
 }
 
+// variants with coarse corrections (two-grid levels), level update fused
+static tile_fn pick_tile_coarse(int W, int rpt, int threads, int hslots) {
+    if (hslots <= 0) hslots = 1;
+#define KKT_TC(w)                                                                  \
+    if (W == w) {                                                                  \
+        if (threads <= 512) {                                                      \
+            switch (rpt) {                                                         \
+                case 1: return pc_tile_sweep<w, 1, 512, true, 2, true>;            \
+                case 2: return pc_tile_sweep<w, 2, 512, true, 3, true>;            \
+                case 3: return pc_tile_sweep<w, 3, 512, true, 4, true>;            \
+                default: return nullptr;                                           \
+            }                                                                      \
+        }                                                                          \
+        return rpt == 1 ? pc_tile_sweep<w, 1, 1024, true, 2, true> : nullptr;      \
+    }
+    KKT_TC(5) KKT_TC(7) KKT_TC(9)
+#undef KKT_TC
+    if (W == 15 && threads > 512 && rpt == 1 && hslots <= 1)
+        return pc_tile_sweep<15, 1, 1024, true, 1, true>;
+    if (W == 15 && threads <= 512) {
+        if (rpt == 1) return pc_tile_sweep<15, 1, 512, true, 2, true>;
+        if (rpt == 2) return pc_tile_sweep<15, 2, 512, true, 3, true>;
+    }
+    if (W == 19 && threads <= 512 && rpt == 1) return pc_tile_sweep<19, 1, 512, true, 2, true>;
+    if (W == 19 && threads <= 512 && rpt == 2) return pc_tile_sweep<19, 2, 512, true, 3, true>;
+    return nullptr;
+}
+
+bool tile_sweep_coarse_available(int W, int rpt, int threads, int hslots) {
+    return threads >= 64 && threads <= 1024 && threads % 64 == 0 && hslots <= rpt + 1 &&
+           pick_tile_coarse(W, rpt, threads, hslots) != nullptr;
+}
+
 bool tile_sweep_fuses_update(int W, int max_terms) {
     return W <= 9 || ((W == 15 || W == 19) && max_terms <= 1);
 }
 
-size_t tile_sweep_lds_bytes(int nk_pad, int its) {
+size_t tile_sweep_lds_bytes(int nk_pad, int its, int coarse_nc, int coarse_nslots, int coarse_jmax,
+                            int coarse_nr_max) {
+    if (coarse_nc > 0)
+        return (2 * (size_t)nk_pad + 3 * (size_t)std::max(1, its) + 1 + (size_t)coarse_nslots +
+                (size_t)coarse_nc + (size_t)coarse_jmax + 2 * (size_t)coarse_nr_max) * sizeof(double) +
+               ((size_t)coarse_nslots + (size_t)coarse_nc + 1 + 2 * (size_t)coarse_jmax + 1) * sizeof(int) +
+               2 * (size_t)coarse_nr_max * sizeof(uint16_t) + 16;
     return (2 * (size_t)nk_pad + 3 * (size_t)std::max(1, its - 1) + 1) * sizeof(double);
 }
 
@@ -890,13 +1178,14 @@ bool tile_sweep_available(int W, int rpt, int threads, int hslots) {
            pick_tile(W, rpt, threads, true, hslots) != nullptr;
 }
 
-int tile_sweep_max_tiles(int W, int rpt, int threads, size_t lds_bytes, int hslots) {
+int tile_sweep_max_tiles(int W, int rpt, int threads, size_t lds_bytes, int hslots, bool coarse) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     // both variants of a width (with / without the level update) must be resident
-    for (int fused = 0; fused < 2; ++fused) {
-        tile_fn f = pick_tile(W, rpt, threads, fused != 0, hslots);
+    // (coarse: the one variant with corrections)
+    for (int fused = coarse ? 1 : 0; fused < 2; ++fused) {
+        tile_fn f = pick_tile(W, rpt, threads, fused != 0, hslots, coarse);
         int per_cu = 0;
         if (!f) return 0;
         if (lds_bytes > 48 * 1024 &&
@@ -913,7 +1202,7 @@ int tile_sweep_max_tiles(int W, int rpt, int threads, size_t lds_bytes, int hslo
 void launch_tile_sweep(hipStream_t s, const TileArgs &a, const TileLevel *d_levels,
                        const int32_t *d_n, const int32_t *d_grow, const uint16_t *d_lcol,
                        const int32_t *d_gpos, const uint8_t *d_rowmask, int ntiles, int threads,
-                       size_t granule_words) {
+                       size_t granule_words, const TileCoarseDev *h_coarse) {
     if (a.nlevels <= 0 || ntiles <= 0) return;
     // tags of an earlier application must not match this one's hand-off numbers
     auto chk = [](hipError_t e, const char *what) {
@@ -927,10 +1216,15 @@ void launch_tile_sweep(hipStream_t s, const TileArgs &a, const TileLevel *d_leve
             launch_zero_bytes(s, a.gnew[i], granule_words * sizeof(unsigned long long));
             launch_zero_bytes(s, a.gold[i], granule_words * sizeof(unsigned long long));
         }
+        if (h_coarse)
+            for (int i = 0; i < 2; ++i) launch_zero_bytes(s, h_coarse->cg[i], h_coarse->cg_bytes);
         chk(hipGetLastError(), "clearing the granule buffers");
     }
-    const size_t lds = tile_sweep_lds_bytes(a.nk_pad, a.its);
-    tile_fn f = pick_tile(a.W, a.rpt, threads, a.fused_update != 0, a.hslots);
+    const size_t lds = h_coarse ? tile_sweep_lds_bytes(a.nk_pad, a.its, h_coarse->nc,
+                                                       h_coarse->nslots, h_coarse->jmax,
+                                                       h_coarse->nr_max)
+                                : tile_sweep_lds_bytes(a.nk_pad, a.its);
+    tile_fn f = pick_tile(a.W, a.rpt, threads, a.fused_update != 0, a.hslots, h_coarse != nullptr);
     if (!f) throw TileLaunchError{"tile sweep program: no kernel variant for this plan"};
     (void)hipGetLastError();
     hipLaunchKernelGGL(f, dim3(ntiles), dim3(threads), lds, s, a, d_levels, d_n, d_grow, d_lcol,

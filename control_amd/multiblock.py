@@ -394,6 +394,17 @@ class MultiBlockSystem:
             kinds = {"stationary": 0, "BE": 1, "CN": 2}
             indptr, indices, data = _as_csr(pc_fn.M)
             bc, pbc = _lib.i32(np.asarray(pc_fn.bc_nodes))
+            co = getattr(pc_fn.schur, "coarse", None)
+            ckw = {}
+            if co is not None and int(co.cycles) > 0:
+                p_ip, p_ix, p_v = _as_csr(co.P)
+                if len(p_ip) - 1 != len(indptr) - 1:
+                    raise ValueError("coarse space: P must have one row per spatial dof")
+                ncoarse = int(co.P.shape[1]) if hasattr(co.P, "shape") else int(p_ix.max()) + 1
+                ckw = dict(coarse_cycles=int(co.cycles), n_coarse=ncoarse,
+                           p_indptr=p_ip.ctypes.data_as(_lib.c_i32p),
+                           p_indices=p_ix.ctypes.data_as(_lib.c_i32p),
+                           p_values=p_v.ctypes.data_as(_lib.c_f64p))
             d = _lib.PcDesc(
                 kind=kinds[pc_fn.kind], n_t=int(pc_fn.n_t), tau=float(pc_fn.tau),
                 beta=float(pc_fn.beta), epsilon=float(pc_fn.epsilon), nx=len(indptr) - 1,
@@ -403,7 +414,7 @@ class MultiBlockSystem:
                 mass_its=int(pc_fn.mass.its), mass_emin=float(pc_fn.mass.emin),
                 mass_emax=float(pc_fn.mass.emax), schur_its=int(pc_fn.schur.its),
                 schur_emin=float(pc_fn.schur.emin), schur_emax=float(pc_fn.schur.emax),
-                schur_eimag=float(getattr(pc_fn.schur, "eimag", 0.0)))
+                schur_eimag=float(getattr(pc_fn.schur, "eimag", 0.0)), **ckw)
             self._ck(self._lib.kkt_set_pc_schur(self._h, C.byref(d)))
             self._pc_state = pc_fn
         elif isinstance(pc_fn, StokesPC):

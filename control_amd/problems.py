@@ -41,10 +41,14 @@ def gpu_system(p, tile_coordinates=True, **kw):
     return g
 
 
-def gpu_pc(p, mass, schur):
-    from .multiblock import ChebSpec, SchurPC
+def gpu_pc(p, mass, schur, coarse=None):
+    """``coarse``: ``(P, cycles)`` -- the two-grid form of the Schur sub-solves."""
+    from .multiblock import ChebSpec, CoarseSpace, SchurPC
+    sch = ChebSpec(*schur)
+    if coarse is not None:
+        sch.coarse = CoarseSpace(coarse[0], int(coarse[1]))
     return SchurPC(kind="CN" if p["CN"] else "BE", M=p["sd"].M, beta=p["beta"],
-                   bc_nodes=p["nodes"], mass=ChebSpec(*mass), schur=ChebSpec(*schur),
+                   bc_nodes=p["nodes"], mass=ChebSpec(*mass), schur=sch,
                    n_t=p["n_t"], tau=p["tau"])
 
 

@@ -13,13 +13,16 @@ def oracle_system(p):
                            n_blocks_11=m, nullspace_0=ns, nullspace_1=ns, CN=p["CN"])
 
 
-def oracle_pc(p, mass, schur):
+def oracle_pc(p, mass, schur, coarse=None):
     from oracle import kkt_oracle as ko
     sd = p["sd"]
     b00, b01, b10, b11 = p["blocks"]
     f = ko.pc_instationary_CN if p["CN"] else ko.pc_instationary_BE
+    sch = ko.ChebSpec(*schur)
+    if coarse is not None:
+        sch.coarse = ko.CoarseSpace(coarse[0], int(coarse[1]))
     return f(sd.M, b01, b10, p["n_t"], p["tau"], p["beta"], p["nodes"],
-             ko.ChebSpec(*mass), ko.ChebSpec(*schur))
+             ko.ChebSpec(*mass), sch)
 
 
 def rel_err(a, b):
