@@ -174,8 +174,9 @@ def build_problem(args):
         # ~coarse_nodes functions, then `schur_its` smoothing sweeps on the upper part of the
         # spectrum (the reference runs BoomerAMG here)
         from control_amd.coarse import multilinear_coarse_space
-        coarse = (multilinear_coarse_space(sd.coords, sd.boundary, target_nodes=args.coarse_nodes),
-                  args.coarse_cycles)
+        # coarse cells of --coarse-cell mesh widths (8: 33^2 coarse functions on 256^2, 9^3 on 64^3)
+        cells = max(2, args.n // max(1, args.coarse_cell))
+        coarse = (multilinear_coarse_space(sd.coords, sd.boundary, cells=cells), args.coarse_cycles)
     return dict(sd=sd, tau=tau, beta=args.beta, n_t=args.n_t, CN=CN, m=blocks[4],
                 blocks=blocks[:4], nodes=sd.boundary, mass=(20,) + mass_bounds, schur=schur,
                 coarse=coarse, share_values=(args.mode == "S"))
@@ -244,7 +245,7 @@ def cpu_baseline(p, its_all, its_one):
     print("[bench] cpu baseline: building the C restatement's matrices", file=sys.stderr,
           flush=True)
     c = cref.CRef(p["blocks"], p["m"], p["sd"].n_dofs, p["nodes"], p["sd"].M, p["n_t"],
-                  p["tau"], p["beta"], p["mass"], p["schur"])
+                  p["tau"], p["beta"], p["mass"], p["schur"], coarse=p.get("coarse"))
     b = common.rng_vector(2 * p["m"] * p["sd"].n_dofs)
     gomp = ctypes.CDLL("libgomp.so.1")
     cores = usable_cores()
@@ -296,7 +297,16 @@ def bench_stokes(args, rank, world, local_rank):
                      args.schur_emin if args.schur_emin != 0.0007 else 0.002, args.schur_emax))
     comm = make_comm(rank, world, local_rank) if world > 1 else None
     device = int(os.environ.get("KKT_DEVICE", local_rank))
-    outer, gpc = common.stokes_gpu(p, specs, comm=comm, device=device)
+    coarse = None
+    if args.coarse_cycles and args.coarse_cycles > 0:
+        # two-grid form of the velocity sub-solves: multilinear coarse functions per velocity
+        # component on cells of --coarse-cell P2 node spacings
+        from control_amd.coarse import multilinear_coarse_space
+        th_ = p["th"]
+        cells = max(2, (2 * n) // max(1, args.coarse_cell))
+        coarse = (multilinear_coarse_space(np.vstack([th_.coords_v, th_.coords_v]), th_.boundary_v,
+                                           cells=cells), args.coarse_cycles)
+    outer, gpc = common.stokes_gpu(p, specs, comm=comm, device=device, coarse=coarse)
     lib, h = outer._lib, outer.handle
     outer._set_pc(gpc)
     info = outer.info()
@@ -379,7 +389,9 @@ def bench_stokes(args, rank, world, local_rank):
                    "unknowns": int(2 * p["m"] * (th.n_v + th.n_p)), "n_v": int(th.n_v),
                    "n_p": int(th.n_p),
                    "krylov": "outer fgmres restart 10; inner gmres, 5 iterations per application",
-                   "preconditioner": f"StokesPC, Chebyshev (its, emin, emax): {specs}",
+                   "preconditioner": f"StokesPC, Chebyshev (its, emin, emax): {specs}" + (
+                       f"; velocity sub-solves {coarse[1]} x [Galerkin correction on "
+                       f"{coarse[0].shape[1]} coarse functions + the schur sweeps]" if coarse else ""),
                    "parallelism": f"time-block rows over {world} GPU(s)",
                    "transport": (getattr(comm, "name", "rccl") if world > 1 else "none"),
                    "sweeps": sweep_plan(inner_info),
@@ -472,15 +484,18 @@ def main():
     # GMRES(10) converges on cfg 2 (scripts/cfg2_convergence.py)
     # (CN: 140 sweeps -- 80 to 100 do not converge there, scripts/cfg2_convergence.py --scheme CN)
     ap.add_argument("--schur-its", type=int, default=None)
-    ap.add_argument("--schur-emin", type=float, default=0.0007)
+    ap.add_argument("--schur-emin", type=float, default=None)
     ap.add_argument("--schur-emax", type=float, default=2.1)
     ap.add_argument("--schur-auto", action="store_true",
                     help="degree and per-matrix intervals of the sub-solves from spectrum "
                          "estimates on the device (kkt_pc_desc.schur_its = -1) instead of the flags")
-    ap.add_argument("--coarse-cycles", type=int, default=0,
+    ap.add_argument("--coarse-cycles", type=int, default=None,
                     help="two-grid form of the Schur sub-solves: cycles of [coarse correction, "
-                         "--schur-its sweeps on [--schur-emin, --schur-emax]] (0: plain Chebyshev)")
-    ap.add_argument("--coarse-nodes", type=int, default=300)
+                         "--schur-its sweeps on [--schur-emin, --schur-emax]]; 0: plain Chebyshev "
+                         "(80 / 140 sweeps on [7e-4, 2.1]: the preconditioner rounds 1 and 2 "
+                         "measured).  Default: 2 on heat2d, 0 elsewhere")
+    ap.add_argument("--coarse-cell", type=int, default=8,
+                    help="coarse cells of this many mesh widths per axis")
     ap.add_argument("--spmv-reps", type=int, default=50)
     ap.add_argument("--cpu-its", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -494,8 +509,21 @@ def main():
                     help="self-launched ranks (--gpus N without a launcher) are stopped after this "
                          "many seconds")
     args = ap.parse_args()
+    if args.coarse_cycles is None:
+        args.coarse_cycles = 2 if args.workload == "heat2d" else 0
+    if args.coarse_cycles > 0 and args.workload != "stokes2d":
+        # measured on 256^2 x 64 (profiles/r03, scripts/r03_tts_quality.py): BE 2 x 8 sweeps on
+        # [0.07, 2.1] -- 17 iterations to the library's stopping test, and the setting that also
+        # converges under fgmres(10) / fgmres(30) (single cycles are faster per iteration, 171
+        # its/s, but stagnate under right-preconditioned FGMRES(10)); CN 2 x 16 on [0.03, 2.1]
+        if args.schur_its is None:
+            args.schur_its = 16 if args.scheme == "CN" else 8
+        if args.schur_emin is None:
+            args.schur_emin = 0.03 if args.scheme == "CN" else 0.07
     if args.schur_its is None:
         args.schur_its = 140 if args.scheme == "CN" and args.workload != "stokes2d" else 80
+    if args.schur_emin is None:
+        args.schur_emin = 0.0007
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return spawn_ranks(args.gpus, sys.argv[1:], args.launch_timeout)
@@ -527,6 +555,7 @@ def main():
         # suggest_chebyshev on the interior-level block of this configuration (4.6 s of host
         # ARPACK, done once offline): (34, 7.44e-3, 2.093)
         a4.schur_its, a4.schur_emin, a4.schur_emax = 34, 7.44e-3, 2.1
+        a4.coarse_cycles = 0      # (3-D: the plain sweeps are at their optimum, profiles/r03)
         a4.steps, a4.warmup, a4.spmv_reps = 10, 2, 10
         o4 = None
         try:

@@ -134,6 +134,7 @@ struct alignas(128) TileLevel {
 struct TileCoarseDev {
     int32_t nc, jmax, n0max, nslots;
     int32_t nr_max;               // most restriction (= prolongation) entries of a tile
+    int32_t cache_lists;          // 1: every tile copies its entries into LDS (they fit)
     const int32_t *nj;            // [ntiles] number of coarse functions the own rows touch
     const int32_t *jglob;         // [ntiles][jmax] their global numbers
     const int32_t *slot0;         // [ntiles] first slot of the tile's partial sums

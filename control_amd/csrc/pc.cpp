@@ -363,11 +363,19 @@ bool SchurPC::prepare_tiles() {
     tile_coarse_ok_ = false;
     if (coarse_cycles_ > 0 && tile_sweep_coarse_available(tp.W, tp.rpt, threads, tp.hslots) &&
         build_tile_coarse()) {
-        const size_t lds_c = tile_sweep_lds_bytes(tp.nk_pad, max_its, h_tile_coarse_.nc,
-                                                  h_tile_coarse_.nslots, h_tile_coarse_.jmax,
-                                                  h_tile_coarse_.nr_max);
-        tile_coarse_ok_ = lds_c <= 160 * 1024 &&
-                          tp.ntiles <= tile_sweep_max_tiles(tp.W, tp.rpt, threads, lds_c, tp.hslots, true);
+        // the tiles' P entries go into LDS when everything fits in 150 KB, else they stay in memory
+        for (int cache = 1; cache >= 0 && !tile_coarse_ok_; --cache) {
+            const size_t lds_c = tile_sweep_lds_bytes(tp.nk_pad, max_its, h_tile_coarse_.nc,
+                                                      h_tile_coarse_.nslots, h_tile_coarse_.jmax,
+                                                      cache ? h_tile_coarse_.nr_max : 0);
+            if (lds_c <= 150 * 1024 &&
+                tp.ntiles <= tile_sweep_max_tiles(tp.W, tp.rpt, threads, lds_c, tp.hslots, true)) {
+                tile_coarse_ok_ = true;
+                h_tile_coarse_.cache_lists = cache;
+                HIPCHK(hipMemcpy(d_tile_coarse_, &h_tile_coarse_, sizeof h_tile_coarse_,
+                                 hipMemcpyHostToDevice));
+            }
+        }
     }
     tp.upload();
     const size_t words = 2 * (size_t)P.nrows;
@@ -514,10 +522,11 @@ bool SchurPC::fuse_tile_run(size_t k, size_t e, std::vector<PcStep> &out) {
         // residency and the dynamic-LDS attribute were checked for tile_lds_checked_ bytes
         const size_t need = coarse ? tile_sweep_lds_bytes(tile_plan_.nk_pad, its, h_tile_coarse_.nc,
                                                           h_tile_coarse_.nslots, h_tile_coarse_.jmax,
-                                                          h_tile_coarse_.nr_max)
+                                                          h_tile_coarse_.cache_lists
+                                                              ? h_tile_coarse_.nr_max : 0)
                                    : tile_sweep_lds_bytes(tile_plan_.nk_pad, its);
         if (need > tile_lds_checked_) {
-            if (need > 160 * 1024 ||
+            if (need > 150 * 1024 ||
                 tile_plan_.ntiles > tile_sweep_max_tiles(tile_plan_.W, tile_plan_.rpt,
                                                          tile_plan_.threads, need, tile_plan_.hslots,
                                                          coarse))

@@ -239,9 +239,12 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     int *CSLc = nullptr, *CIPc = nullptr, *RIPc = nullptr, *JGc = nullptr;
     uint16_t *RROWc = nullptr, *PKc = nullptr;
     int pe0[RPT], pe1[RPT];
+    bool c_cached = true;    // the tile's P entries are in LDS (3-D: 8 per row, they stay in memory)
+    int c_re0 = 0, c_pq0 = 0;
     if constexpr (COARSE) {
         const TileCoarseDev *cd = A.coarse;
-        const int nrm = cd->nr_max;
+        c_cached = cd->cache_lists != 0;
+        const int nrm = c_cached ? cd->nr_max : 0;
         RWc = EC + c_jmax;
         PWc = RWc + nrm;
         CSLc = reinterpret_cast<int *>(PWc + nrm);
@@ -253,15 +256,19 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
         const gci_p rip = (gci_p)cd->r_ip + (size_t)tile * c_jmax;
         const gci_p pip = (gci_p)cd->p_ip + (size_t)tile * c_n0max;
         const int re0 = rip[0], re1 = rip[c_nj], pq0 = pip[0], pq1 = pip[nt[0]];
+        c_re0 = re0;
+        c_pq0 = pq0;
         const gcu16_p rrow = (gcu16_p)cd->r_row, pk = (gcu16_p)cd->p_k;
         const gcd_p rw = (gcd_p)cd->r_w, pw = (gcd_p)cd->p_w;
-        for (int i = tid; i < re1 - re0; i += T) {
-            RWc[i] = rw[re0 + i];
-            RROWc[i] = rrow[re0 + i];
-        }
-        for (int i = tid; i < pq1 - pq0; i += T) {
-            PWc[i] = pw[pq0 + i];
-            PKc[i] = pk[pq0 + i];
+        if (c_cached) {
+            for (int i = tid; i < re1 - re0; i += T) {
+                RWc[i] = rw[re0 + i];
+                RROWc[i] = rrow[re0 + i];
+            }
+            for (int i = tid; i < pq1 - pq0; i += T) {
+                PWc[i] = pw[pq0 + i];
+                PKc[i] = pk[pq0 + i];
+            }
         }
         const gci_p cslot = (gci_p)cd->c_slot, cip = (gci_p)cd->c_ip;
         for (int i = tid; i < c_nslots; i += T) CSLc[i] = cslot[i];
@@ -792,8 +799,15 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                     for (int k = wave; k < c_nj; k += nwaves) {
                         const int e0 = RIPc[k], e1 = RIPc[k + 1];
                         double a = 0.0;
-                        for (int e = e0 + lane; e < e1; e += 64)
-                            a = __builtin_fma(RWc[e], Rb[RROWc[e]], a);
+                        if (c_cached) {
+                            for (int e = e0 + lane; e < e1; e += 64)
+                                a = __builtin_fma(RWc[e], Rb[RROWc[e]], a);
+                        } else {
+                            const gcu16_p rrow = (gcu16_p)cd->r_row + c_re0;
+                            const gcd_p rw = (gcd_p)cd->r_w + c_re0;
+                            for (int e = e0 + lane; e < e1; e += 64)
+                                a = __builtin_fma(rw[e], Rb[rrow[e]], a);
+                        }
 #pragma unroll
                         for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
                         if (lane == 0) publish(rc_, c_slot0 + k, a, cepoch);
@@ -875,8 +889,15 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                         const int r = sl * T + tid;
                         if (r < n0) {
                             double a = 0.0;
-                            for (int e = pe0[sl]; e < pe1[sl]; ++e)
-                                a = __builtin_fma(PWc[e], EC[PKc[e]], a);
+                            if (c_cached) {
+                                for (int e = pe0[sl]; e < pe1[sl]; ++e)
+                                    a = __builtin_fma(PWc[e], EC[PKc[e]], a);
+                            } else {
+                                const gcu16_p pk = (gcu16_p)cd->p_k + c_pq0;
+                                const gcd_p pw = (gcd_p)cd->p_w + c_pq0;
+                                for (int e = pe0[sl]; e < pe1[sl]; ++e)
+                                    a = __builtin_fma(pw[e], EC[pk[e]], a);
+                            }
                             Xc[r] = cyc == 0 ? a : Xc[r] + a;
                         }
                     }
@@ -1222,7 +1243,7 @@ void launch_tile_sweep(hipStream_t s, const TileArgs &a, const TileLevel *d_leve
     }
     const size_t lds = h_coarse ? tile_sweep_lds_bytes(a.nk_pad, a.its, h_coarse->nc,
                                                        h_coarse->nslots, h_coarse->jmax,
-                                                       h_coarse->nr_max)
+                                                       h_coarse->cache_lists ? h_coarse->nr_max : 0)
                                 : tile_sweep_lds_bytes(a.nk_pad, a.its);
     tile_fn f = pick_tile(a.W, a.rpt, threads, a.fused_update != 0, a.hslots, h_coarse != nullptr);
     if (!f) throw TileLaunchError{"tile sweep program: no kernel variant for this plan"};

@@ -71,9 +71,9 @@ def stokes_problem(n=4, n_t=4, beta=1.0e-2, T=2.0, CN=False, share=True):
     return dict(th=th, tau=tau, beta=beta, n_t=n_t, CN=CN, m=bl["m"], blocks=bl)
 
 
-def stokes_gpu(p, specs=STOKES_SPECS, options=None, comm=None, device=0):
+def stokes_gpu(p, specs=STOKES_SPECS, options=None, comm=None, device=0, coarse=None):
     """Outer system, velocity KKT system and pressure commutator on the GPU + the StokesPC."""
-    from .multiblock import (ChebSpec, ConstantNullspace, DirichletBCNullspace,
+    from .multiblock import (ChebSpec, CoarseSpace, ConstantNullspace, DirichletBCNullspace,
                              MultiBlockSystem, SchurPC, StokesPC)
     th, m, CN, bl = p["th"], p["m"], p["CN"], p["blocks"]
     nsv = DirichletBCNullspace(th.boundary_v)
@@ -93,9 +93,12 @@ def stokes_gpu(p, specs=STOKES_SPECS, options=None, comm=None, device=0):
     # velocity and commutator systems by their levels -- the same [lo, hi) on a rank)
     commutator = MultiBlockSystem(th.n_p, th.n_p, *bl["commutator"], n_blocks_00=m,
                                   n_blocks_11=m, options=options, comm=comm, device=device)
+    schur = ChebSpec(*specs["schur"])
+    if coarse is not None:      # (P, cycles): two-grid form of the velocity sub-solves
+        schur.coarse = CoarseSpace(coarse[0], int(coarse[1]))
     inner_pc = SchurPC(kind="CN" if CN else "BE", M=th.M_v, beta=p["beta"],
                        bc_nodes=th.boundary_v, mass=ChebSpec(*specs["mass"]),
-                       schur=ChebSpec(*specs["schur"]), n_t=p["n_t"], tau=p["tau"])
+                       schur=schur, n_t=p["n_t"], tau=p["tau"])
     gpc = StokesPC(inner=inner, inner_pc=inner_pc, commutator=commutator, B=th.B, K_p=th.K_p,
                    M_p=th.M_p, kp=ChebSpec(*specs["kp"]), mp=ChebSpec(*specs["mp"]),
                    n_p_blocks=m, b_scale=p["tau"], post_scale=1.0 / p["tau"]**2, cn=CN)

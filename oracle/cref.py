@@ -35,7 +35,10 @@ class RefPc(C.Structure):
                 ("G", C.POINTER(Csr)), ("Gdinv", C.POINTER(f64p)), ("mask", u8p),
                 ("mass_its", C.c_int32), ("schur_its", C.c_int32),
                 ("mass_emin", C.c_double), ("mass_emax", C.c_double),
-                ("schur_emin", C.c_double), ("schur_emax", C.c_double)]
+                ("schur_emin", C.c_double), ("schur_emax", C.c_double),
+                ("coarse_cycles", C.c_int32), ("nc", C.c_int32),
+                ("P", C.POINTER(Csr)), ("PT", C.POINTER(Csr)),
+                ("FEinv", C.POINTER(f64p)), ("GEinv", C.POINTER(f64p))]
 
 
 def usable_cores(cap=16):
@@ -73,7 +76,9 @@ def load(build=True):
 class CRef:
     """BE heat-control system + block-Schur preconditioner in the C restatement."""
 
-    def __init__(self, blocks, m, nx, nodes, M, n_t, tau, beta, mass, schur, epsilon=1.0e-3):
+    def __init__(self, blocks, m, nx, nodes, M, n_t, tau, beta, mass, schur, epsilon=1.0e-3,
+                 coarse=None):
+        """``coarse``: ``(P, cycles)`` -- the two-grid form of the Schur sub-solves."""
         self.lib = load()
         self._keep = []
         self.m, self.nx = m, nx
@@ -125,8 +130,11 @@ class CRef:
             if key not in scache:
                 At = ko.assemble_with_bcs(blk if c == 0.0 else blk + c * M, nodes)
                 dinv = np.ascontiguousarray(1.0 / At.diagonal())
-                self._keep += [At, dinv]
-                scache[key] = (csr(At), dinv)
+                einv = None
+                if coarse is not None:
+                    einv = np.ascontiguousarray(ko.coarse_inverse(At, ko.CoarseSpace(*coarse)))
+                self._keep += [At, dinv, einv]
+                scache[key] = (csr(At), dinv, einv)
             return scache[key]
         Mt = ko.assemble_with_bcs(M, nodes)
         mdinv = np.ascontiguousarray(1.0 / Mt.diagonal())
@@ -150,6 +158,17 @@ class CRef:
         pc.mask = mask.ctypes.data_as(u8p)
         pc.mass_its, pc.mass_emin, pc.mass_emax = mass
         pc.schur_its, pc.schur_emin, pc.schur_emax = schur[:3]     # (real intervals: BE heat control)
+        if coarse is not None:
+            Pm = sp.csr_matrix(coarse[0])
+            Pm.sort_indices()
+            PT = sp.csr_matrix(Pm.T)
+            PT.sort_indices()
+            pc.coarse_cycles, pc.nc = int(coarse[1]), Pm.shape[1]
+            pc.P, pc.PT = one(Pm), one(PT)
+            fe = (f64p * n)(*[f[2].ctypes.data_as(f64p) for f in F])
+            ge = (f64p * n)(*[g[2].ctypes.data_as(f64p) for g in G])
+            self._keep += [fe, ge]
+            pc.FEinv, pc.GEinv = fe, ge
         self.pc = pc
 
     def mult(self, x):

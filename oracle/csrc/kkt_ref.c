@@ -115,6 +115,82 @@ static void cheb(const csr_t *A, const double *dinv, const double *b, double emi
     memcpy(out, pk, (size_t)n * sizeof(double));
 }
 
+/* Two-grid form of a sub-solve (oracle.kkt_oracle.coarse_chebyshev): cycles x [x += P Einv P^T
+ * (b - A x); `its` Jacobi-Chebyshev sweeps from x (KSPSolve_Chebyshev with a non-zero guess)].
+ * PT = P^T as CSR (nc rows); Einv = (P^T A P)^-1, nc x nc row-major; x (n), r (n), rc, ec (nc). */
+static void coarse_cheb(const csr_t *A, const double *dinv, const double *b, double emin,
+                        double emax, int its, int cycles, const csr_t *Pm, const csr_t *PT,
+                        const double *Einv, int nc, double *out, double *w0, double *w1, double *w2,
+                        double *r, double *rc, double *ec) {
+    const int32_t n = A->nrows;
+    const double scale = 2.0 / (emax + emin), alpha = 1.0 - scale * emin;
+    const double mu = 1.0 / alpha, omegaprod = 2.0 / alpha;
+    double *x = w0;      /* the iterate between cycles */
+    for (int c = 0; c < cycles; ++c) {
+        /* residual of the current iterate (zero guess in the first cycle) */
+#pragma omp parallel for schedule(static)
+        for (int32_t i = 0; i < n; ++i) {
+            double s = 0.0;
+            if (c > 0)
+                for (int32_t k = A->indptr[i]; k < A->indptr[i + 1]; ++k)
+                    s = fma(A->vals[k], x[A->indices[k]], s);
+            r[i] = b[i] - s;
+        }
+#pragma omp parallel for schedule(static)
+        for (int32_t j = 0; j < nc; ++j) {
+            double s = 0.0;
+            for (int32_t k = PT->indptr[j]; k < PT->indptr[j + 1]; ++k)
+                s = fma(PT->vals[k], r[PT->indices[k]], s);
+            rc[j] = s;
+        }
+#pragma omp parallel for schedule(static)
+        for (int32_t j = 0; j < nc; ++j) {
+            double s = 0.0;
+            for (int32_t k = 0; k < nc; ++k) s = fma(Einv[(size_t)j * nc + k], rc[k], s);
+            ec[j] = s;
+        }
+        /* p0 = x + P ec, into r (the residual is used up) */
+#pragma omp parallel for schedule(static)
+        for (int32_t i = 0; i < n; ++i) {
+            double s = 0.0;
+            for (int32_t k = Pm->indptr[i]; k < Pm->indptr[i + 1]; ++k)
+                s = fma(Pm->vals[k], ec[Pm->indices[k]], s);
+            r[i] = c > 0 ? x[i] + s : s;
+        }
+        /* `its` sweeps from p0: p1 = p0 + scale dinv (b - A p0), then the recurrence; the three
+         * vectors rotate through r, w1, w2 */
+        double *pkm1 = r, *pk = w1, *pkp1 = w2;
+        double c_km1 = 1.0, c_k = mu;
+#pragma omp parallel for schedule(static)
+        for (int32_t i = 0; i < n; ++i) {
+            double s = 0.0;
+            for (int32_t k = A->indptr[i]; k < A->indptr[i + 1]; ++k)
+                s = fma(A->vals[k], pkm1[A->indices[k]], s);
+            pk[i] = pkm1[i] + scale * (dinv[i] * (b[i] - s));
+        }
+        for (int i2 = 1; i2 < its; ++i2) {
+            const double c_kp1 = 2.0 * mu * c_k - c_km1;
+            const double omega = omegaprod * c_k / c_kp1;
+#pragma omp parallel for schedule(static)
+            for (int32_t i = 0; i < n; ++i) {
+                double s = 0.0;
+                for (int32_t k = A->indptr[i]; k < A->indptr[i + 1]; ++k)
+                    s = fma(A->vals[k], pk[A->indices[k]], s);
+                const double z = dinv[i] * (b[i] - s);
+                pkp1[i] = (1.0 - omega) * pkm1[i] + omega * pk[i] + (scale * omega) * z;
+            }
+            double *t = pkm1;
+            pkm1 = pk;
+            pk = pkp1;
+            pkp1 = t;
+            c_km1 = c_k;
+            c_k = c_kp1;
+        }
+        memcpy(x, pk, (size_t)n * sizeof(double));
+    }
+    memcpy(out, x, (size_t)n * sizeof(double));
+}
+
 typedef struct {
     int32_t n_t, nx;
     double tau, beta, epsilon;
@@ -131,6 +207,11 @@ typedef struct {
     const uint8_t *mask;
     int32_t mass_its, schur_its;
     double mass_emin, mass_emax, schur_emin, schur_emax;
+    /* two-grid form of the Schur sub-solves (coarse_cycles == 0: plain Chebyshev) */
+    int32_t coarse_cycles, nc;
+    const csr_t *P, *PT;
+    const double *const *FEinv;   /* n_t: (P^T F_i P)^-1 */
+    const double *const *GEinv;
 } ref_pc_t;
 
 /* u = P pc_linear(P b) + (I - P) b, BE (control.py:2191-2438 inside preconditioner.py:562-656) */
@@ -140,8 +221,10 @@ void ref_pc_apply_BE(const ref_pc_t *P, const double *b, double *u) {
     const double tau = P->tau, eps = P->epsilon;
     double *bc = (double *)malloc(N * sizeof(double));
     double *B = (double *)malloc((size_t)n * nx * sizeof(double));
-    double *w = (double *)malloc((size_t)4 * nx * sizeof(double));
+    double *w = (double *)malloc(((size_t)5 * nx + 2 * (size_t)(P->coarse_cycles > 0 ? P->nc : 0)) *
+                                 sizeof(double));
     double *t = w + 3 * (int64_t)nx;
+    double *cr = w + 4 * (int64_t)nx, *crc = w + 5 * (int64_t)nx, *cec = crc + P->nc;
 #pragma omp parallel for schedule(static)
     for (int64_t p = 0; p < N; ++p) bc[p] = P->mask[p % nx] ? 0.0 : b[p];
     const double *b0 = bc, *b1 = bc + (int64_t)n * nx;
@@ -187,6 +270,11 @@ void ref_pc_apply_BE(const ref_pc_t *P, const double *b, double *u) {
 #pragma omp parallel for schedule(static)
             for (int32_t r = 0; r < nx; ++r) Bi[r] = P->mask[r] ? 0.0 : Bi[r] - t[r];
         }
+        if (P->coarse_cycles > 0)
+            coarse_cheb(&P->F[i], P->Fdinv[i], Bi, P->schur_emin, P->schur_emax, P->schur_its,
+                        P->coarse_cycles, P->P, P->PT, P->FEinv[i], P->nc, BLK(u1, i), w, w + nx,
+                        w + 2 * (int64_t)nx, cr, crc, cec);
+        else
         cheb(&P->F[i], P->Fdinv[i], Bi, P->schur_emin, P->schur_emax, P->schur_its, BLK(u1, i), w,
              w + nx, w + 2 * (int64_t)nx, 1);
     }
@@ -206,6 +294,11 @@ void ref_pc_apply_BE(const ref_pc_t *P, const double *b, double *u) {
 #pragma omp parallel for schedule(static)
             for (int32_t r = 0; r < nx; ++r) Bi[r] = P->mask[r] ? 0.0 : Bi[r] - t[r];
         }
+        if (P->coarse_cycles > 0)
+            coarse_cheb(&P->G[i], P->Gdinv[i], Bi, P->schur_emin, P->schur_emax, P->schur_its,
+                        P->coarse_cycles, P->P, P->PT, P->GEinv[i], P->nc, BLK(u1, i), w, w + nx,
+                        w + 2 * (int64_t)nx, cr, crc, cec);
+        else
         cheb(&P->G[i], P->Gdinv[i], Bi, P->schur_emin, P->schur_emax, P->schur_its, BLK(u1, i), w,
              w + nx, w + 2 * (int64_t)nx, 1);
     }

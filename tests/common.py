@@ -33,7 +33,7 @@ def rel_err(a, b):
 
 
 
-def stokes_oracle(p, specs=STOKES_SPECS):
+def stokes_oracle(p, specs=STOKES_SPECS, coarse=None):
     from oracle import kkt_oracle as ko
     th, m, CN, bl = p["th"], p["m"], p["CN"], p["blocks"]
     kw = dict(sub_n_blocks_00_0=m, sub_n_blocks_11_0=m) if CN else {}
@@ -42,9 +42,12 @@ def stokes_oracle(p, specs=STOKES_SPECS):
                                              for _ in range(2 * m)),
                            nullspace_1=tuple(ko.ConstantNullspace() for _ in range(2 * m)),
                            CN=CN, **kw)
+    schur = ko.ChebSpec(*specs["schur"])
+    if coarse is not None:
+        schur.coarse = ko.CoarseSpace(coarse[0], int(coarse[1]))
     opc = ko.pc_instationary_incompressible(
         th.M_v, bl["inner"], th.B, th.M_p, th.K_p, bl["commutator"], p["n_t"], p["tau"],
-        p["beta"], th.boundary_v, ko.ChebSpec(*specs["mass"]), ko.ChebSpec(*specs["schur"]),
+        p["beta"], th.boundary_v, ko.ChebSpec(*specs["mass"]), schur,
         ko.ChebSpec(*specs["kp"]), ko.ChebSpec(*specs["mp"]), CN=CN)
     return osys, opc
 

@@ -197,3 +197,45 @@ def run_rank_timeout(rank, world, conns, out_q):
     except Exception as e:
         import traceback
         out_q.put((rank, "error", traceback.format_exc() + repr(e)))
+
+
+def run_rank_coarse(rank, world, conns, out_q):
+    """Time-sharded solve with the two-grid sub-solves (tile program per rank): shard of the
+    preconditioner application against the single-rank oracle, solve against the one-rank GPU."""
+    try:
+        import common
+        from control_amd.coarse import multilinear_coarse_space
+        from control_amd.dist import CallbackComm, PipeTransport, shard_range
+        p = common.heat_problem(n=48, n_t=8, beta=1e-4)
+        m, nx = p["m"], p["sd"].n_dofs
+        lo, hi = shard_range(m, rank, world)
+        tr = PipeTransport(rank, world, conns)
+        comm = CallbackComm(rank, world, tr.allreduce, tr.sendrecv)
+        co = (multilinear_coarse_space(p["sd"].coords, p["nodes"], cells=6), 1)
+        mass, schur = (20, 0.5, 2.0), (8, 0.07, 2.1)
+        g = common.gpu_system(p, comm=comm)
+        osys = common.oracle_system(p)
+
+        def shard(v):
+            V = np.asarray(v).reshape(2 * m, nx)
+            return np.concatenate([V[lo:hi].ravel(), V[m + lo:m + hi].ravel()])
+        x = common.rng_vector(osys.N)
+        e_pc = common.rel_err(g.pc_apply(shard(x), common.gpu_pc(p, mass, schur, coarse=co)),
+                              shard(osys.pc_apply(common.oracle_pc(p, mass, schur, coarse=co), x)))
+        import bench
+        g0, g1 = bench.readme_rhs(p)
+        sp_ = {"linear_solver": "gmres", "gmres_restart": 10, "maximum_iterations": 100,
+               "relative_tolerance": 1e-6, "absolute_tolerance": 0.0, "monitor_convergence": False}
+        u0, u1 = np.zeros((hi - lo, nx)), np.zeros((hi - lo, nx))
+        r = g.solve(u0, u1, g0[lo:hi].copy(), g1[lo:hi].copy(), solver_parameters=sp_,
+                    pc_fn=common.gpu_pc(p, mass, schur, coarse=co))
+        one = common.gpu_system(p)
+        v0, v1 = np.zeros((m, nx)), np.zeros((m, nx))
+        r1 = one.solve(v0, v1, g0, g1, solver_parameters=sp_,
+                       pc_fn=common.gpu_pc(p, mass, schur, coarse=co))
+        e_u = common.rel_err(np.vstack([u0, u1]), np.vstack([v0[lo:hi], v1[lo:hi]]))
+        out_q.put((rank, "ok", dict(e_pc=e_pc, its=r.its, its_one=r1.its, e_u=e_u,
+                                    form=int(g.info()["sweep_form"]))))
+    except Exception as e:
+        import traceback
+        out_q.put((rank, "error", traceback.format_exc() + repr(e)))

@@ -62,3 +62,39 @@ def test_coarse_solve_needs_fewer_sweeps_and_no_more_iterations():
     # (left-preconditioned GMRES stops on the preconditioned residual: two preconditioners, two
     # stopping points)
     assert common.rel_err(out["coarse"][1], out["plain"][1]) < 1e-2
+
+
+@pytest.mark.parametrize("CN", [False, True])
+def test_stokes_velocity_sub_solves_in_two_grid_form(CN):
+    """The StokesPC's nested velocity solve with two-grid sub-solves (vector P2: one copy of the
+    multilinear coarse functions per velocity component): one application against the oracle."""
+    p = common.stokes_problem(n=8, n_t=5 if CN else 4, CN=CN)
+    th = p["th"]
+    P = multilinear_coarse_space(np.vstack([th.coords_v, th.coords_v]), th.boundary_v, cells=4)
+    assert P.shape == (th.n_v, 2 * 25)
+    specs = dict(common.STOKES_SPECS, schur=(6, 0.07, 2.2))
+    osys, opc = common.stokes_oracle(p, specs, coarse=(P, 1))
+    outer, gpc = common.stokes_gpu(p, specs, coarse=(P, 1))
+    x = common.rng_vector(osys.N)
+    # (nested 5-iteration GMRES: the bar of tests/test_gpu_stokes.py)
+    assert common.rel_err(outer.pc_apply(x, gpc), osys.pc_apply(opc, x)) < (1e-7 if CN else 1e-4)
+
+
+def test_coarse_tile_program_soak_and_sharded_equivalents():
+    """The tile program with coarse corrections, repeated: every application equals the first bit
+    for bit (the coarse residual is summed in a fixed order) and the plain launches to round-off
+    (other association of the restriction sums); no time-out."""
+    p = common.heat_problem(n=96, n_t=8, beta=1e-4)
+    co = _coarse(p, 12, 2)
+    schur = (6, 0.07, 2.1)
+    x = common.rng_vector(2 * p["m"] * p["sd"].n_dofs)
+    g = common.gpu_system(p, options={"prog_mode": "tile"})
+    pc = common.gpu_pc(p, MASS, schur, coarse=co)
+    y0 = g.pc_apply(x, pc)
+    assert g.info()["sweep_form"] == 3
+    for _ in range(60):
+        assert np.array_equal(g.pc_apply(x, pc), y0)
+    assert g.info()["program_fallbacks"] == 0
+    plain = common.gpu_system(p, options={"persistent": "0"}).pc_apply(
+        x, common.gpu_pc(p, MASS, schur, coarse=co))
+    assert common.rel_err(y0, plain) < 1e-12
