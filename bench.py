@@ -308,7 +308,8 @@ def bench_stokes(args, rank, world, local_rank):
                                            cells=cells), args.coarse_cycles)
     outer, gpc = common.stokes_gpu(p, specs, comm=comm, device=device, coarse=coarse)
     lib, h = outer._lib, outer.handle
-    outer._set_pc(gpc)
+    if not args.only_spmv:
+        outer._set_pc(gpc)
     info = outer.info()
     n_local = info["n_local"]
 
@@ -324,6 +325,18 @@ def bench_stokes(args, rank, world, local_rank):
     outer._ck(lib.kkt_time_apply(h, d_x, d_y, 5, C.byref(ms)))
     outer._ck(lib.kkt_time_apply(h, d_x, d_y, args.spmv_reps, C.byref(ms)))
     spmv_ms = ms.value / args.spmv_reps
+    if args.only_spmv:
+        if rank == 0:
+            alg_ = info["bytes_streamed"]
+            th_ = p["th"]
+            print(json.dumps({
+                "config": {"workload": (f"2-D Stokes control, Taylor-Hood P2-P1 {n}x{n}, n_t={n_t}, "
+                                        f"beta={beta:g}, T={args.T:g}, {args.scheme}, mode {args.mode}"),
+                           "unknowns": int(2 * p["m"] * (th_.n_v + th_.n_p))},
+                "roofline": {"achieved": alg_ / (spmv_ms * 1e-3) / 1e9,
+                             "frac": alg_ / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_launch": alg_, "launch_ms": spmv_ms}}))
+        return 0
     outer._ck(lib.kkt_time_pc_apply(h, d_x, d_y, 1, C.byref(ms)))
     outer._ck(lib.kkt_time_pc_apply(h, d_x, d_y, 3, C.byref(ms)))
     pc_ms = ms.value / 3
@@ -596,8 +609,9 @@ def measure_heat(args, rank, world, local_rank, tts):
     gsys = common.gpu_system(p, device=device, comm=comm, share_values=p["share_values"],
                              tile_coordinates=not args.no_tile_coordinates)
     lib, h = gsys._lib, gsys.handle
-    gpc = common.gpu_pc(p, p["mass"], p["schur"], coarse=p.get("coarse"))
-    gsys._set_pc(gpc)
+    if not args.only_spmv:       # (counter-collection passes of the operator need no preconditioner)
+        gpc = common.gpu_pc(p, p["mass"], p["schur"], coarse=p.get("coarse"))
+        gsys._set_pc(gpc)
     gsys._ck(lib.kkt_sync(h))
     t_setup = time.perf_counter() - t_setup     # CSR -> device storage + preconditioner build
     info = gsys.info()
@@ -627,9 +641,13 @@ def measure_heat(args, rank, world, local_rank, tts):
     csr_bytes = info["bytes_algorithmic"]
     achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9
     if args.only_spmv:
-        return {"kkt_apply_ms": spmv_ms, "achieved_GBs": achieved,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "csr_formula_bytes_per_launch": csr_bytes}
+        workload_ = (f"{'2-D' if args.workload == 'heat2d' else '3-D'} heat control, "
+                     f"{args.n}^{2 if args.workload == 'heat2d' else 3} P1, n_t={args.n_t}, "
+                     f"beta={args.beta:g}, T={args.T:g}, {args.scheme}, mode {args.mode}")
+        return {"config": {"workload": workload_, "unknowns": int(2 * p["m"] * p["sd"].n_dofs)},
+                "roofline": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": spmv_ms,
+                             "csr_formula_bytes_per_launch": csr_bytes}}
     gsys._ck(lib.kkt_time_pc_apply(h, d_x, d_y, 2, C.byref(ms)))
     gsys._ck(lib.kkt_time_pc_apply(h, d_x, d_y, 5, C.byref(ms)))
     pc_ms = ms.value / 5
