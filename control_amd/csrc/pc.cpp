@@ -325,29 +325,33 @@ bool SchurPC::prepare_tiles() {
     // coordinates of the rows, if the caller gave them (kkt_set_tile_coordinates)
     const double *tc = (S_.tile_dim > 0 && (int64_t)S_.tile_coords.size() == P.nrows * S_.tile_dim)
                            ? S_.tile_coords.data() : nullptr;
+    const int xh = coarse_cycles_ > 0 ? 2 : 0;     // extra hand-offs per cycle of a two-grid level
     if (tw) {
         threads = 64 * std::max(1, std::min(16, std::atoi(tw)));
         // (the depth model must only consider what a kernel variant exists for: wide rows have
         // one or two row slots, and a deeper plan that needs more would lose the tile form)
         if (!build_tile_plan(P, ntiles, depth, threads,
                              std::max(1, tile_sweep_max_rpt(P.max_width, threads)), tile_plan_, hm,
-                             schur_its_, tc, S_.tile_dim, tile_sweep_max_hslots))
+                             schur_its_, tc, S_.tile_dim, tile_sweep_max_hslots, xh))
             return false;
     } else {
         TilePlan big;
         const bool ok_big = tile_sweep_max_rpt(P.max_width, 1024) >= 1 &&
                             build_tile_plan(P, ntiles, depth, 1024, 1, big, hm, schur_its_, tc, S_.tile_dim,
-                                            tile_sweep_max_hslots) &&
+                                            tile_sweep_max_hslots, xh) &&
                             tile_sweep_available(big.W, big.rpt, 1024, big.hslots);
         const bool ok_small = tile_sweep_max_rpt(P.max_width, 512) >= 1 &&
                               build_tile_plan(P, ntiles, depth, 512,
                                               tile_sweep_max_rpt(P.max_width, 512), tile_plan_, hm,
-                                              schur_its_, tc, S_.tile_dim, tile_sweep_max_hslots) &&
+                                              schur_its_, tc, S_.tile_dim, tile_sweep_max_hslots, xh) &&
                               tile_sweep_available(tile_plan_.W, tile_plan_.rpt, 512, tile_plan_.hslots);
         if (!ok_big && !ok_small) return false;
         // (1 024 threads only where more than 512 rows are computed: with fewer, half of the 16
         // waves never have a live row -- 32^3: 293 its/s with 512 threads, 283 with 1 024)
-        if (ok_big && (!ok_small || (big.max_rows > 512 && big.model_us <= tile_plan_.model_us)))
+        // (two-grid levels: 16 waves also share the coarse exchange's work -- measured on cfg 2:
+        // 1 024 threads at depth 5 118 its/s, 512 threads at depth 4 103)
+        if (ok_big && (!ok_small || (big.max_rows > 512 && big.model_us <= tile_plan_.model_us) ||
+                       (coarse_cycles_ > 0 && big.max_own > 128)))
             tile_plan_ = big;
         threads = tile_plan_.threads;
     }

@@ -59,7 +59,8 @@ struct TilePlan {
 bool build_tile_plan(const Pattern &P, int ntiles, int depth, int threads, int max_rpt,
                      TilePlan &out, const uint8_t *mask = nullptr, int its = 0,
                      const double *coords = nullptr, int dim = 0,
-                     int (*max_hslots)(int W, int rpt, int threads) = nullptr);
+                     int (*max_hslots)(int W, int rpt, int threads) = nullptr,
+                     int extra_handoffs = 0);
 // `max_hslots` (may be null: rpt + 1): ring-entry slots per thread the kernel variant with `rpt`
 // row slots has; a plan whose rings need more is not made (a deeper one would lose the tile form).
 
