@@ -734,6 +734,7 @@ def measure_heat(args, rank, world, local_rank, tts):
                  "converged": bool(s_reason.value > 0), "iterations": int(s_its.value),
                  "seconds": s_dt.value}
     info_end = gsys.info()       # after every leg: what ran, and whether anything fell back
+    last_error = lib.kkt_last_error(h).decode() if info_end.get("program_fallbacks") else ""
     gsys.close()
     if rank != 0:
         return None
@@ -784,7 +785,7 @@ def measure_heat(args, rank, world, local_rank, tts):
     if plan["program_fallbacks"]:
         out["config"]["warning"] = ("a persistent sweep program timed out during this run and the "
                                     "preconditioner fell back to plain launches: value and "
-                                    "pc_apply_ms measure that form (see config.sweeps)")
+                                    "pc_apply_ms measure that form (see config.sweeps): " + last_error)
     if sweeps is not None:
         # HBM-side bytes of one application (all sweep launches) from the committed PMC passes
         per_launch = measured_sweep_traffic(workload, out["config"]["preconditioner"],

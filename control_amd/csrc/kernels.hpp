@@ -135,6 +135,7 @@ struct TileCoarseDev {
     int32_t nc, jmax, n0max, nslots;
     int32_t nr_max;               // most restriction (= prolongation) entries of a tile
     int32_t cache_lists;          // 1: every tile copies its entries into LDS (they fit)
+    int32_t cache_einv;           // 1: ... and keeps its rows of (P^T A P)^-1 there across levels
     const int32_t *nj;            // [ntiles] number of coarse functions the own rows touch
     const int32_t *jglob;         // [ntiles][jmax] their global numbers
     const int32_t *slot0;         // [ntiles] first slot of the tile's partial sums
@@ -177,7 +178,8 @@ int tile_sweep_max_rpt(int W, int threads);   // most row slots per thread of an
 // rows); wide rows (3-D P1) have no registers for it: the update stays a launch of its own
 bool tile_sweep_fuses_update(int W, int max_terms);   // update terms of any level of the run
 size_t tile_sweep_lds_bytes(int nk_pad, int its, int coarse_nc = 0, int coarse_nslots = 0,
-                            int coarse_jmax = 0, int coarse_nr_max = 0);
+                            int coarse_jmax = 0, int coarse_nr_max = 0,
+                            bool coarse_einv_rows = false);
 // workgroups of `threads` that are certainly co-resident (one per CU)
 int tile_sweep_max_tiles(int W, int rpt, int threads, size_t lds_bytes, int hslots,
                          bool coarse = false);

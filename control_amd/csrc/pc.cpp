@@ -368,14 +368,16 @@ bool SchurPC::prepare_tiles() {
     if (coarse_cycles_ > 0 && tile_sweep_coarse_available(tp.W, tp.rpt, threads, tp.hslots) &&
         build_tile_coarse()) {
         // the tiles' P entries go into LDS when everything fits in 150 KB, else they stay in memory
-        for (int cache = 1; cache >= 0 && !tile_coarse_ok_; --cache) {
+        // (and, room permitting, its rows of the coarse inverse: cache = 2)
+        for (int cache = 2; cache >= 0 && !tile_coarse_ok_; --cache) {
             const size_t lds_c = tile_sweep_lds_bytes(tp.nk_pad, max_its, h_tile_coarse_.nc,
                                                       h_tile_coarse_.nslots, h_tile_coarse_.jmax,
-                                                      cache ? h_tile_coarse_.nr_max : 0);
+                                                      cache ? h_tile_coarse_.nr_max : 0, cache == 2);
             if (lds_c <= 150 * 1024 &&
                 tp.ntiles <= tile_sweep_max_tiles(tp.W, tp.rpt, threads, lds_c, tp.hslots, true)) {
                 tile_coarse_ok_ = true;
-                h_tile_coarse_.cache_lists = cache;
+                h_tile_coarse_.cache_lists = cache >= 1;
+                h_tile_coarse_.cache_einv = cache == 2;
                 HIPCHK(hipMemcpy(d_tile_coarse_, &h_tile_coarse_, sizeof h_tile_coarse_,
                                  hipMemcpyHostToDevice));
             }
@@ -527,7 +529,8 @@ bool SchurPC::fuse_tile_run(size_t k, size_t e, std::vector<PcStep> &out) {
         const size_t need = coarse ? tile_sweep_lds_bytes(tile_plan_.nk_pad, its, h_tile_coarse_.nc,
                                                           h_tile_coarse_.nslots, h_tile_coarse_.jmax,
                                                           h_tile_coarse_.cache_lists
-                                                              ? h_tile_coarse_.nr_max : 0)
+                                                              ? h_tile_coarse_.nr_max : 0,
+                                                          h_tile_coarse_.cache_einv != 0)
                                    : tile_sweep_lds_bytes(tile_plan_.nk_pad, its);
         if (need > tile_lds_checked_) {
             if (need > 150 * 1024 ||

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     // masked off, another process holding wave slots -- the resident tiles would each spin 2^21
     // times in their first hand-off before giving up.  Instead every tile checks in on a counter
     // (it only ever grows: each launch adds exactly gridDim.x, so the value a tile must see is the
-    // next multiple above what its own atomic returned) and waits a bounded ~50 us for the others;
+    // next multiple above what its own atomic returned) and waits a bounded ~5 ms for the others;
     // a tile that does not see them all marks the launch as abandoned, and every tile -- those
     // still waiting and those scheduled later -- leaves at once.  The host then falls back to
     // plain launches (kkt_info.program_fallbacks).
@@ -131,7 +131,9 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
         const unsigned long long target = (old / nt_ + 1ull) * nt_;
         int bad = 0;
         unsigned long long seen = old;
-        for (int spin = 0; spin < 256; ++spin) {
+        // (4 096 polls of ~1.2 us: 5 ms -- long against any launch skew, 400 times shorter than
+        // the bounded spin of a hand-off)
+        for (int spin = 0; spin < 4096; ++spin) {
             seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (seen >= target) break;
             if (__hip_atomic_load(bail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == target) break;
@@ -241,6 +243,12 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     int pe0[RPT], pe1[RPT];
     bool c_cached = true;    // the tile's P entries are in LDS (3-D: 8 per row, they stay in memory)
     int c_re0 = 0, c_pq0 = 0;
+    // this tile's rows of (P^T A P)^-1 in LDS while consecutive levels share the matrix (time-
+    // invariant operators): 12 rows of 1 089 doubles per tile and correction were 27 MB over the
+    // chip, about half of the exchange's 10 us
+    double *EINVc = nullptr;
+    bool c_einv_cache = false;
+    const void *einv_key = nullptr;
     if constexpr (COARSE) {
         const TileCoarseDev *cd = A.coarse;
         c_cached = cd->cache_lists != 0;
@@ -253,6 +261,10 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
         JGc = RIPc + (c_jmax + 1);
         RROWc = reinterpret_cast<uint16_t *>(JGc + c_jmax);
         PKc = RROWc + nrm;
+        c_einv_cache = cd->cache_einv != 0;
+        // (8-byte aligned: behind the 2-byte lists, rounded up)
+        EINVc = reinterpret_cast<double *>(
+            (reinterpret_cast<uintptr_t>(PKc + nrm) + 7) & ~(uintptr_t)7);
         const gci_p rip = (gci_p)cd->r_ip + (size_t)tile * c_jmax;
         const gci_p pip = (gci_p)cd->p_ip + (size_t)tile * c_n0max;
         const int re0 = rip[0], re1 = rip[c_nj], pq0 = pip[0], pq1 = pip[nt[0]];
@@ -589,7 +601,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
             asm volatile("" : "+v"(dinv[sl]));
             asm volatile("" : "+v"(b[sl]));
         }
-        if (stamps && tid == 0) sstat[7] += wall_clock64() - t_mark;   // prologue up to the update
+        if (!COARSE && stamps && tid == 0) sstat[7] += wall_clock64() - t_mark;   // prologue up to the update
         const double post1 = L.post1, post2 = L.post2;
         int cr;
         {
@@ -789,6 +801,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                     cstep(1, n0, 0.0, 0.0, 0.0, false, 1.0, 1.0);
                 }
                 lds_barrier();
+                lap(1, cyc == 0 ? 0 : 1);      // (stamps: the residual step counts as a step)
                 // ---- restriction: partial sums over the own rows for the coarse functions they
                 // touch, a wave per function, lanes stride its list, fixed butterfly
                 ++cepoch;
@@ -873,10 +886,24 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                     }
                     lds_barrier();
                     // ---- this tile's rows of (P^T A P)^-1, a wave per coarse function
+                    if (c_einv_cache && (const void *)einv != einv_key) {
+                        // (the iterates' barrier above ordered every earlier read of EINVc)
+                        for (int k = wave; k < c_nj; k += nwaves) {
+                            const gcd_p row = einv + (size_t)JGc[k] * c_nc;
+                            for (int q = lane; q < c_nc; q += 64) EINVc[(size_t)k * c_nc + q] = row[q];
+                        }
+                        einv_key = (const void *)einv;
+                        // (a wave reads back only the row it wrote: no barrier needed)
+                    }
                     for (int k = wave; k < c_nj; k += nwaves) {
-                        const gcd_p row = einv + (size_t)JGc[k] * c_nc;
                         double a = 0.0;
-                        for (int q = lane; q < c_nc; q += 64) a = __builtin_fma(row[q], RC[q], a);
+                        if (c_einv_cache) {
+                            const double *row = EINVc + (size_t)k * c_nc;
+                            for (int q = lane; q < c_nc; q += 64) a = __builtin_fma(row[q], RC[q], a);
+                        } else {
+                            const gcd_p row = einv + (size_t)JGc[k] * c_nc;
+                            for (int q = lane; q < c_nc; q += 64) a = __builtin_fma(row[q], RC[q], a);
+                        }
 #pragma unroll
                         for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
                         if (lane == 0) EC[k] = a;
@@ -904,6 +931,11 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                 }
                 // (the barrier inside the hand-off orders these stores before anyone's gathers)
                 lds_barrier();
+                if (stamps) {      // the coarse exchange, restriction to prolongation: slot 7
+                    const unsigned long long now = wall_clock64();
+                    if (tid == 0) sstat[7] += now - t_mark;
+                    t_mark = now;
+                }
                 handoff(false);
                 cr = depth;
                 // ---- smoothing sweeps from the corrected iterate
@@ -1171,7 +1203,11 @@ bool tile_sweep_fuses_update(int W, int max_terms) {
 }
 
 size_t tile_sweep_lds_bytes(int nk_pad, int its, int coarse_nc, int coarse_nslots, int coarse_jmax,
-                            int coarse_nr_max) {
+                            int coarse_nr_max, bool coarse_einv_rows) {
+    if (coarse_nc > 0 && coarse_einv_rows)
+        return tile_sweep_lds_bytes(nk_pad, its, coarse_nc, coarse_nslots, coarse_jmax,
+                                    coarse_nr_max, false) +
+               (size_t)coarse_jmax * coarse_nc * sizeof(double) + 8;
     if (coarse_nc > 0)
         return (2 * (size_t)nk_pad + 3 * (size_t)std::max(1, its) + 1 + (size_t)coarse_nslots +
                 (size_t)coarse_nc + (size_t)coarse_jmax + 2 * (size_t)coarse_nr_max) * sizeof(double) +
@@ -1243,7 +1279,8 @@ void launch_tile_sweep(hipStream_t s, const TileArgs &a, const TileLevel *d_leve
     }
     const size_t lds = h_coarse ? tile_sweep_lds_bytes(a.nk_pad, a.its, h_coarse->nc,
                                                        h_coarse->nslots, h_coarse->jmax,
-                                                       h_coarse->cache_lists ? h_coarse->nr_max : 0)
+                                                       h_coarse->cache_lists ? h_coarse->nr_max : 0,
+                                                       h_coarse->cache_einv != 0)
                                 : tile_sweep_lds_bytes(a.nk_pad, a.its);
     tile_fn f = pick_tile(a.W, a.rpt, threads, a.fused_update != 0, a.hslots, h_coarse != nullptr);
     if (!f) throw TileLaunchError{"tile sweep program: no kernel variant for this plan"};

@@ -291,7 +291,7 @@ def test_sweep_program_timeout_falls_back_to_plain_launches():
 
 def test_tiles_that_are_not_co_resident_are_detected_at_kernel_entry():
     """The tile programs need every workgroup of their grid running at once.  Each tile checks in
-    on a counter when the kernel starts and waits a bounded ~0.3 ms for the others; if they do not
+    on a counter when the kernel starts and waits a bounded ~5 ms for the others; if they do not
     all arrive (test hook: tile 0 never checks in -- what a masked-off CU or a busy device looks
     like to the others) every tile leaves at once, the host says so on stderr, rebuilds the
     preconditioner as plain launches and redoes the application: same result, one fall-back, in
