@@ -136,12 +136,18 @@ class ShardedHeatSystem:
                 return dinv * rhs
             return ko.chebyshev_jacobi(At, dinv, rhs, spec.emin, spec.emax, spec.its, spec.eimag)
 
+        co = getattr(schur, "coarse", None)
+
         def solve(blk, c, rhs):
             key = (id(blk), c)
             if key not in cache:
                 At = ko.assemble_with_bcs(blk if c == 0.0 else blk + c * M, nodes)
-                cache[key] = (At, 1.0 / At.diagonal(), blk)
-            At, dinv, _ = cache[key]
+                # two-grid form: the sub-solve of a level is local to the rank that owns it
+                cache[key] = (At, 1.0 / At.diagonal(), blk,
+                              ko.coarse_inverse(At, co) if co is not None else None)
+            At, dinv, _, Einv = cache[key]
+            if co is not None:
+                return ko.coarse_chebyshev(At, dinv, rhs, schur, Einv)
             return inner(At, dinv, schur, rhs)
 
         def bc(v):

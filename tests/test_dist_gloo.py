@@ -21,7 +21,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, CN, q):
+def _worker(rank, world, port, CN, q, two_grid=False):
     try:
         sys.path.insert(0, HERE)
         sys.path.insert(0, os.path.dirname(HERE))
@@ -56,9 +56,16 @@ def _worker(rank, world, port, CN, q):
         osys = common.oracle_system(p)
         mass, schur = (20, 0.5, 2.0), (12, 0.08, 2.1)
         from oracle import kkt_oracle as ko
-        opc = common.oracle_pc(p, mass, schur)
-        spc = ssys.make_pc(p["n_t"], p["tau"], p["beta"], ko.ChebSpec(*mass),
-                           ko.ChebSpec(*schur))
+        coarse, sspec = None, ko.ChebSpec(*schur)
+        if two_grid:
+            # two-grid form of the Schur sub-solves (2 cycles of [coarse correction, 4 sweeps])
+            from control_amd.coarse import multilinear_coarse_space
+            P = multilinear_coarse_space(p["sd"].coords, p["nodes"], cells=4)
+            schur = (4, 0.07, 2.1)
+            coarse, sspec = (P, 2), ko.ChebSpec(*schur)
+            sspec.coarse = ko.CoarseSpace(P, 2)
+        opc = common.oracle_pc(p, mass, schur, coarse=coarse)
+        spc = ssys.make_pc(p["n_t"], p["tau"], p["beta"], ko.ChebSpec(*mass), sspec)
 
         def shard(v):
             V = np.asarray(v).reshape(2 * m, nx)
@@ -87,13 +94,14 @@ def _worker(rank, world, port, CN, q):
         q.put((rank, "error", traceback.format_exc() + repr(e)))
 
 
-@pytest.mark.parametrize("CN", [False, True])
-def test_two_rank_sharded_algorithm_matches_single_rank(CN):
+@pytest.mark.parametrize("CN,two_grid", [(False, False), (True, False), (False, True)])
+def test_two_rank_sharded_algorithm_matches_single_rank(CN, two_grid):
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     world, port = 2, _free_port()
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, CN, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, CN, q, two_grid))
+             for r in range(world)]
     for pr in procs:
         pr.start()
     res = {}
