@@ -288,13 +288,16 @@ def bench_stokes(args, rank, world, local_rank):
     CN = args.scheme == "CN"
     print("[bench] assembling the synthetic Stokes system", file=sys.stderr, flush=True)
     p = common.stokes_problem(n=n, n_t=n_t, beta=beta, T=args.T, CN=CN, share=(args.mode == "S"))
+    # velocity sub-solves and the pressure-Laplacian solve of the commutator: degree and
+    # per-matrix intervals from the library's spectrum estimates (its = -1: 1.6 sqrt(kappa)
+    # sweeps) unless --schur-its / --kp-its hand-set them.  The pressure solve keeps its own
+    # polynomial whatever form the velocity sub-solves take.
     specs = dict(mass=(20, 0.3924, 2.0598), mp=(20, 0.5, 2.0),
-                 # Jacobi-scaled P2 stiffness: lambda_max = 2.19 (measured with eigsh)
-                 schur=(args.schur_its if args.schur_its != 80 else 40,
-                        args.schur_emin if args.schur_emin != 0.0007 else 0.002,
-                        max(args.schur_emax, 2.25)),
-                 kp=(args.schur_its if args.schur_its != 80 else 40,
-                     args.schur_emin if args.schur_emin != 0.0007 else 0.002, args.schur_emax))
+                 schur=(((8, 0.07, 2.25) if args.coarse_cycles > 0 else (-1, 0.0, 0.0))
+                        if args.stokes_schur_its is None else
+                        (args.stokes_schur_its, args.stokes_schur_emin, max(args.schur_emax, 2.25))),
+                 kp=((-1, 0.0, 0.0) if args.kp_its < 0 else
+                     (args.kp_its, args.kp_emin, args.schur_emax)))
     comm = make_comm(rank, world, local_rank) if world > 1 else None
     device = int(os.environ.get("KKT_DEVICE", local_rank))
     coarse = None
@@ -363,6 +366,45 @@ def bench_stokes(args, rank, world, local_rank):
     stages = stage_breakdown(outer, lib, h, d_x, d_u, d_x, d_y, n_local, min(args.steps, 10), 1,
                              with_pc_stages=False)
     inner_info = gpc.inner.info() if hasattr(gpc, "inner") else {}
+    # ---- time to solution (one GPU): b = A x* for a smooth x* (velocity zero on the boundary,
+    # pressure blocks of zero mean), zero initial guess, outer FGMRES(10) to rtol 1e-6; says
+    # whether a cheaper preconditioner application was bought with more outer iterations
+    t_sol = None
+    if world == 1:
+        th_ = p["th"]
+        m2 = 2 * p["m"]
+        Xv, Xp = th_.coords_v, th_.coords_p
+        sv = np.sin(0.5 * np.pi * Xv[:, 0]) * np.sin(0.5 * np.pi * Xv[:, 1])
+        sv = np.concatenate([sv, -0.5 * sv])
+        sv[th_.boundary_v] = 0.0
+        sq = np.cos(0.5 * np.pi * Xp[:, 0]) * np.cos(np.pi * Xp[:, 1])
+        sq -= sq.mean()
+        xs = np.concatenate([np.concatenate([(1.0 + 0.1 * k) * sv for k in range(m2)]),
+                             np.concatenate([(1.0 - 0.05 * k) * sq for k in range(m2)])])
+        d_s, d_b = dvec(xs), dvec()
+        outer._ck(lib.kkt_apply_device(h, d_s, d_b))
+        outer._ck(lib.kkt_vec_upload(h, d_u, _lib.f64(np.zeros(n_local))[1]))
+        outer._ck(lib.kkt_set_krylov(h, 1, -1, 10, 1e-6, 0.0, 1e300, 200))
+        its_s, reason, nh, rn = C.c_int(), C.c_int(), C.c_int(), C.c_double()
+        outer._ck(lib.kkt_sync(h))
+        t0 = time.perf_counter()
+        outer._ck(lib.kkt_solve_device(h, d_b, d_u, C.byref(its_s), C.byref(reason),
+                                       C.byref(rn), None, 0, C.byref(nh)))
+        outer._ck(lib.kkt_sync(h))
+        dt_s = time.perf_counter() - t0
+        got = np.empty(n_local)
+        outer._ck(lib.kkt_vec_download(h, d_u, _lib.f64(got)[1]))
+        nv_all = m2 * th_.n_v
+        gp = got[nv_all:].reshape(m2, th_.n_p)
+        gp = gp - gp.mean(axis=1, keepdims=True)     # pressures are fixed up to a constant
+        t_sol = {"rhs": "A x* for a smooth x* (velocity sin sin, pressure cos cos of zero mean)",
+                 "stopping_test": "outer fgmres restart 10, rtol 1e-6, max 200",
+                 "converged": bool(reason.value > 0), "iterations": int(its_s.value),
+                 "seconds": dt_s,
+                 "velocity_error": float(np.linalg.norm(got[:nv_all] - xs[:nv_all])
+                                         / np.linalg.norm(xs[:nv_all])),
+                 "pressure_error": float(np.linalg.norm(gp.ravel() - xs[nv_all:])
+                                         / np.linalg.norm(xs[nv_all:]))}
     # the nested velocity solve's block-Schur preconditioner, itemised (5 applications of it and
     # 5 velocity-operator applies make up most of one StokesPC application)
     try:
@@ -408,7 +450,8 @@ def bench_stokes(args, rank, world, local_rank):
                    "parallelism": f"time-block rows over {world} GPU(s)",
                    "transport": (getattr(comm, "name", "rccl") if world > 1 else "none"),
                    "sweeps": sweep_plan(inner_info),
-                   "pc_apply_ms": pc_ms, "kkt_apply_ms": spmv_ms},
+                   "pc_apply_ms": pc_ms, "kkt_apply_ms": spmv_ms,
+                   "time_to_solution": t_sol},
         "stages": stages,
         "roofline": roof}))
     return 0 if ok else 4
@@ -507,6 +550,9 @@ def main():
                          "--schur-its sweeps on [--schur-emin, --schur-emax]]; 0: plain Chebyshev "
                          "(80 / 140 sweeps on [7e-4, 2.1]: the preconditioner rounds 1 and 2 "
                          "measured).  Default: 2 on heat2d, 0 elsewhere")
+    ap.add_argument("--kp-its", type=int, default=-1,
+                    help="stokes2d: sweeps of the pressure-Laplacian solve (-1: from the spectrum)")
+    ap.add_argument("--kp-emin", type=float, default=0.002)
     ap.add_argument("--coarse-cell", type=int, default=8,
                     help="coarse cells of this many mesh widths per axis")
     ap.add_argument("--spmv-reps", type=int, default=50)
@@ -524,6 +570,9 @@ def main():
     args = ap.parse_args()
     if args.coarse_cycles is None:
         args.coarse_cycles = 2 if args.workload == "heat2d" else 0
+    # (the Stokes leg hand-sets its velocity sub-solves only when the flags are given)
+    args.stokes_schur_its = args.schur_its
+    args.stokes_schur_emin = 0.07 if args.schur_emin is None else args.schur_emin
     if args.coarse_cycles > 0 and args.workload != "stokes2d":
         # measured on 256^2 x 64 (profiles/r03, scripts/r03_tts_quality.py): BE 2 x 8 sweeps on
         # [0.07, 2.1] -- 17 iterations to the library's stopping test, and the setting that also
