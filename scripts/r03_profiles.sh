@@ -7,6 +7,7 @@ cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 o=gpurun_out/r03_prof
 mkdir -p $o
+MODE=$1      # "", "pmc-only" or "nopmc"
 if [ "$1" != "pmc-only" ]; then
 timeout -k 10 900 python bench.py > $o/bench_r03.json 2> $o/bench_r03.err
 echo "bench rc=$?"
@@ -14,6 +15,7 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $o/heat -o h --output-form
 echo "kernel stats rc=$?"
 fi
 pmc() {   # name, then the bench arguments (each pass bounded: a hung pass must not take the call)
+  [ "$MODE" = "nopmc" ] && return 0
   name=$1; shift
   for c in FETCH_SIZE WRITE_SIZE; do
     KKT_NO_GRAPH=1 timeout -k 10 240 rocprofv3 --pmc $c --kernel-trace -d $o/${name}_$c -o p --output-format csv -- python3 bench.py --no-cpu-baseline --no-config4 "$@" > $o/${name}_$c.json 2> $o/${name}_$c.err
@@ -34,9 +36,10 @@ for extra in "--coarse-cycles 0" "--scheme CN" "--scheme CN --coarse-cycles 0" "
   timeout -k 10 300 python bench.py --no-cpu-baseline --no-config4 $extra >> $o/other_configs.jsonl 2>> $o/other.err
   echo "variant [$extra] rc=$?"
 done
-timeout -k 10 300 python bench.py --workload stokes2d --steps 10 --warmup 2 > $o/bench_stokes2d.json 2> $o/stokes.err
+timeout -k 10 400 python bench.py --workload stokes2d --steps 10 --warmup 2 > $o/bench_stokes2d.json 2> $o/stokes.err
 echo "stokes rc=$?"
-timeout -k 10 300 python bench.py --workload stokes2d --steps 10 --warmup 2 --coarse-cycles 1 --schur-its 8 --schur-emin 0.07 --coarse-cell 16 > $o/bench_stokes2d_two_grid.json 2>> $o/stokes.err
-echo "stokes two-grid rc=$?"
+# the round-2 preconditioner of this leg (plain polynomials of 40 sweeps): faster per iteration, does not converge
+timeout -k 10 400 python bench.py --workload stokes2d --steps 10 --warmup 2 --coarse-cycles 0 --schur-its 40 --schur-emin 0.002 --kp-its 40 --kp-emin 0.002 --tts-max-it 200 > $o/bench_stokes2d_round2_pc.json 2>> $o/stokes.err
+echo "stokes round-2 pc rc=$?"
 python3 scripts/r03_tts_quality.py > $o/tts_quality.txt 2>&1
 ls $o

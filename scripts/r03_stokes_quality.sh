@@ -7,15 +7,30 @@ mkdir -p $o
 : > $o/lines.jsonl
 run() {
   echo "== $*" >> $o/err.log
-  timeout -k 10 280 python bench.py --workload stokes2d --steps 10 --warmup 2 "$@" >> $o/lines.jsonl 2>> $o/err.log
+  timeout -k 10 330 python bench.py --workload stokes2d --steps 10 --warmup 2 "$@" >> $o/lines.jsonl 2>> $o/err.log
   echo "[$*] rc=$?"
 }
+if [ "$1" = "third" ]; then
+run --coarse-cycles 3 --coarse-cell 8 --kp-its 300 --kp-emin 0.0005
+run --coarse-cycles 2 --coarse-cell 8 --kp-its 600 --kp-emin 0.0002
+run --coarse-cycles 2 --coarse-cell 8 --schur-its 12 --schur-emin 0.07 --kp-its 300 --kp-emin 0.0005
+run --coarse-cycles 2 --coarse-cell 8 --kp-its 400 --kp-emin 0.0003
+elif [ "$1" = "second" ]; then
+run --coarse-cycles 1 --coarse-cell 8 --kp-its 160
+run --coarse-cycles 2 --coarse-cell 8 --kp-its 300 --kp-emin 0.0005
+run --coarse-cycles 2 --coarse-cell 8 --kp-its 80
+run --coarse-cycles 2 --coarse-cell 16 --kp-its 160
+run --coarse-cycles 3 --coarse-cell 8 --kp-its 160
+else
 run
-run --schur-its 40 --schur-emin 0.002 --kp-its 40
 run --schur-its 80 --schur-emin 0.002 --kp-its 80
+run --schur-its 160 --schur-emin 0.002 --kp-its 160
 run --coarse-cycles 2 --coarse-cell 8
-run --coarse-cycles 1 --coarse-cell 16
-run --coarse-cycles 2 --coarse-cell 8 --kp-its 40
+run --coarse-cycles 3 --coarse-cell 8
+run --coarse-cycles 2 --coarse-cell 8 --schur-its 12 --schur-emin 0.04
+run --coarse-cycles 2 --coarse-cell 16 --schur-its 16 --schur-emin 0.02
+run --coarse-cycles 2 --coarse-cell 8 --kp-its 160
+fi
 python3 - <<'P'
 import json
 for l in open('gpurun_out/st_quality/lines.jsonl'):
