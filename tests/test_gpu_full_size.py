@@ -233,7 +233,7 @@ def test_config3_stokes_operator_and_preconditioner():
 
 def test_config3_stokes_two_grid_preconditioner():
     """The same StokesPC with the two-grid form of the velocity sub-solves (2 cycles of [Galerkin
-    correction on 31 x 31 multilinear functions per component, 8 sweeps on [0.07, 2.25]]): one
+    correction on 33 x 33 multilinear functions per component, 8 sweeps on [0.07, 2.25]]): one
     application against the oracle at full size."""
     from control_amd.coarse import multilinear_coarse_space
     t0 = time.time()
@@ -250,7 +250,7 @@ def test_config3_stokes_two_grid_preconditioner():
     _log("+ oracle StokesPC", t0)
     err = common.rel_err(got, ref)
     print(f"[full-size] config 3 two-grid StokesPC rel. deviation {err:.2e}", flush=True)
-    # measured 9.0e-8: on top of the nested GMRES, the 1922 x 1922 coarse inverses come from
+    # measured 9.0e-8: on top of the nested GMRES, the 2178 x 2178 coarse inverses come from
     # Gauss-Jordan on the device here and from LAPACK in the oracle
     assert err < 1e-6
     assert gpc.inner.info()["program_fallbacks"] == 0
