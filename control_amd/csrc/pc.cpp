@@ -345,7 +345,17 @@ bool SchurPC::prepare_tiles() {
                                               tile_sweep_max_rpt(P.max_width, 512), tile_plan_, hm,
                                               schur_its_, tc, S_.tile_dim, tile_sweep_max_hslots, xh) &&
                               tile_sweep_available(tile_plan_.W, tile_plan_.rpt, 512, tile_plan_.hslots);
-        if (!ok_big && !ok_small) return false;
+        // wide rows (P2: 19 entries) have no 1 024-thread variant -- 128 registers do not hold a
+        // row -- but a 768-thread one: 12 waves with one row each instead of 8 with two
+        TilePlan mid;
+        const bool ok_mid = !ok_big && tile_sweep_max_rpt(P.max_width, 768) >= 1 &&
+                            build_tile_plan(P, ntiles, depth, 768, 1, mid, hm, schur_its_, tc, S_.tile_dim,
+                                            tile_sweep_max_hslots, xh) &&
+                            tile_sweep_available(mid.W, mid.rpt, 768, mid.hslots);
+        if (!ok_big && !ok_small && !ok_mid) return false;
+        if (ok_mid && (!ok_small || (mid.max_rows > 512 && mid.model_us <= tile_plan_.model_us) ||
+                       (coarse_cycles_ > 0 && mid.max_own > 128)))
+            tile_plan_ = mid;
         // (1 024 threads only where more than 512 rows are computed: with fewer, half of the 16
         // waves never have a live row -- 32^3: 293 its/s with 512 threads, 283 with 1 024)
         // (two-grid levels: 16 waves also share the coarse exchange's work -- measured on cfg 2:

@@ -20,7 +20,8 @@ struct Spectrum {
     int steps;
 };
 Spectrum jacobi_spectrum(System &S, int pattern, const double *vals, const double *dinv,
-                         const uint8_t *rowmask, int max_steps);
+                         const uint8_t *rowmask, int max_steps,
+                         bool zero_mean = false);
 // spectral radius of D^-1 S for the values `skew_vals` of a skew-symmetric matrix on `pattern`
 // (power iteration on -(D^-1 S)^2; an estimate from below)
 double jacobi_skew_radius(System &S, int pattern, const double *skew_vals, const double *dinv,
@@ -100,6 +101,7 @@ class SchurPC : public PcBase {
     int bc_set() const { return bc_set_; }
     // degree and interval the sub-solves of a typical time level run with (given or derived)
     int schur_its() const { return schur_its_; }
+    int coarse_cycles() const { return coarse_cycles_; }
     double typical_emin() const { return typical_emin_; }
     double typical_emax() const { return typical_emax_; }
     int64_t n_launches() const { return (int64_t)steps_.size(); }

@@ -197,6 +197,22 @@ StokesPC::StokesPC(System &outer, System &inner, System &commutator, const kkt_p
     if (kp_its < 0 || kp_emin <= 0) {
         const SchurPC *sp = dynamic_cast<const SchurPC *>(inner.pc.get());
         if (!sp) fail(KKT_ERR_STATE, "automatic K_p sweeps need the built-in preconditioner on the inner system");
+        if (sp->coarse_cycles() > 0) {
+            // The velocity sub-solves are two-grid cycles: their few smoothing sweeps and their
+            // interval say nothing about K_p.  Estimate K_p itself -- it is singular (constants),
+            // so the Lanczos recurrence starts from a zero-mean vector and sees the non-zero
+            // spectrum only -- and give the solve 5 sqrt(kappa) sweeps, at most 600: the outer
+            // iteration is sensitive to this solve (128^2 x 32, profiles/r03/stokes_quality.txt:
+            // 160 / 300 / 600 sweeps -> 195 / 145 / 100 outer iterations).
+            const Spectrum ks = jacobi_spectrum(S_, Kp_.pat, Kp_.vals, Kp_.dinv, nullptr, 400, true);
+            if (!(ks.emin > 0.0) || !(ks.emax > ks.emin)) fail(KKT_ERR_STATE, "no Chebyshev interval for K_p");
+            if (kp_emin <= 0) {
+                kp_emin = 0.85 * ks.emin;      // Ritz values approach the ends from inside
+                kp_emax = 1.05 * ks.emax;
+            }
+            if (kp_its < 0)
+                kp_its = std::max(4, std::min(600, (int)std::ceil(5.0 * std::sqrt(kp_emax / kp_emin))));
+        }
         if (kp_its < 0) kp_its = sp->schur_its();
         if (kp_emin <= 0) {
             kp_emin = sp->typical_emin();

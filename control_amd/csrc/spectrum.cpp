@@ -67,8 +67,11 @@ std::vector<double> tridiag_eigenvalues(std::vector<double> d, std::vector<doubl
 
 }  // namespace
 
+// `zero_mean`: the matrix is singular with the constants in its kernel (a Neumann Laplacian):
+// the start vector gets zero mean, so the recurrence stays in the range and the smallest Ritz
+// value approaches the smallest NON-ZERO eigenvalue.
 Spectrum jacobi_spectrum(System &S, int pattern, const double *vals, const double *dinv,
-                         const uint8_t *rowmask, int max_steps) {
+                         const uint8_t *rowmask, int max_steps, bool zero_mean) {
     const Pattern &P = S.patterns[pattern];
     const int64_t n = P.nrows;
     hipStream_t st = S.stream;
@@ -93,6 +96,12 @@ Spectrum jacobi_spectrum(System &S, int pattern, const double *vals, const doubl
             HIPCHK(hipMemcpy(m.data(), rowmask, n, hipMemcpyDeviceToHost));
             for (int64_t i = 0; i < n; ++i)
                 if (m[i]) h[i] = 0.0;
+        }
+        if (zero_mean) {
+            long double sum = 0.0L;
+            for (int64_t i = 0; i < n; ++i) sum += h[i];
+            const double mean = (double)(sum / (long double)n);
+            for (int64_t i = 0; i < n; ++i) h[i] -= mean;
         }
         HIPCHK(hipMemcpy(r, h.data(), n * sizeof(double), hipMemcpyHostToDevice));
     }

@@ -1162,6 +1162,8 @@ static tile_fn pick_tile(int W, int rpt, int threads, bool fused = true, int hsl
         return fused ? pc_tile_sweep<19, 1, 512, true> : pc_tile_sweep<19, 1, 512, false>;
     if (W == 19 && threads <= 512 && rpt == 2)      // 215 registers
         return fused ? pc_tile_sweep<19, 2, 512, true> : pc_tile_sweep<19, 2, 512, false>;
+    if (W == 19 && threads > 512 && threads <= 768 && rpt == 1)
+        return fused ? pc_tile_sweep<19, 1, 768, true> : pc_tile_sweep<19, 1, 768, false>;
     return nullptr;
 }
 
@@ -1190,6 +1192,10 @@ static tile_fn pick_tile_coarse(int W, int rpt, int threads, int hslots) {
     }
     if (W == 19 && threads <= 512 && rpt == 1) return pc_tile_sweep<19, 1, 512, true, 2, true>;
     if (W == 19 && threads <= 512 && rpt == 2) return pc_tile_sweep<19, 2, 512, true, 3, true>;
+    // (two-grid levels are short chains of steps: 16 waves with one row each run a step's 19
+    // gathers in half the time of 8 waves with two)
+    if (W == 19 && threads > 512 && threads <= 768 && rpt == 1)
+        return pc_tile_sweep<19, 1, 768, true, 2, true>;
     return nullptr;
 }
 

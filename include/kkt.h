@@ -231,9 +231,11 @@ typedef struct kkt_pc_stokes_desc {
     const int32_t *mp_indptr, *mp_indices;    /* M_p: np x np */
     const double *mp_values;
     int kp_its;              /* Jacobi-Chebyshev steps replacing the BoomerAMG cycle on K_p;
-                                -1: the degree of the inner system's sub-solves */
+                                -1: the degree of the inner system's sub-solves (inner sub-solves in
+                                two-grid form: 5 sqrt(kappa) of K_p's own non-zero spectrum, <= 600) */
     double kp_emin, kp_emax; /* kp_emin <= 0: lower bound of the inner sub-solves, upper bound
-                                estimated from K_p */
+                                estimated from K_p (two-grid inner sub-solves: both ends estimated
+                                from K_p, constants deflated) */
     int mp_its;              /* control.py:957-971: 20 (0: one Jacobi application, :973-979) */
     double mp_emin, mp_emax;
 } kkt_pc_stokes_desc;
