@@ -303,6 +303,13 @@ class StokesPC : public PcBase {
     double *halo_a_ = nullptr, *halo_b_ = nullptr;   // CN on time shards: neighbour blocks of the T scans
     std::vector<void *> owned_;
     std::vector<RowLaunch> lin_, kp_steps_, mp_steps_;
+    // the two Chebyshev chains (hundreds of small launches on fixed buffers) replayed as graphs
+    struct Chain {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        bool failed = false;
+    } kp_chain_, mp_chain_;
+    void run_chain(Chain &c, const std::vector<RowLaunch> &steps);
     DevMat upload(int64_t nrows, int64_t ncols, const int32_t *ip, const int32_t *ix,
                   const double *v, bool want_dinv);
     void emit_cheb(std::vector<RowLaunch> &dst, const DevMat &A, int its, double emin, double emax,

@@ -31,6 +31,11 @@ static RowLaunch upload_launch(const Pattern &P, std::vector<RowOp> &ops) {
     L.max_slices = P.nslices;
     L.R = P.R;
     L.uniform_w = P.uniform_w;
+    // every op applies one and the same matrix: the four-blocks-per-thread form applies
+    L.shared_matrix = !ops.empty();
+    for (const RowOp &op : ops)
+        L.shared_matrix = L.shared_matrix && op.nterms == 1 && op.t[0].vals == ops[0].t[0].vals &&
+                          op.col == ops[0].col && op.rowmask == ops[0].rowmask;
     L.d_ops = dev_upload(ops.data(), ops.size());
     return L;
 }
@@ -228,6 +233,10 @@ StokesPC::StokesPC(System &outer, System &inner, System &commutator, const kkt_p
 }
 
 StokesPC::~StokesPC() {
+    for (Chain *c : {&kp_chain_, &mp_chain_}) {
+        if (c->exec) (void)hipGraphExecDestroy(c->exec);
+        if (c->graph) (void)hipGraphDestroy(c->graph);
+    }
     for (auto *v : {&lin_, &kp_steps_, &mp_steps_})
         for (auto &L : *v)
             if (L.d_ops) (void)hipFree(L.d_ops);
@@ -274,14 +283,48 @@ void StokesPC::run() {
                               up >= 0 ? halo_b_ : nullptr);
         if (dn >= 0) S_.comm->sendrecv(first_b, np_, dn, nullptr, 0, -1, st);
     }
-    for (const RowLaunch &L : kp_steps_)
-        launch_rowops(st, L.d_ops, L.nops, L.max_slices, L.R, B, 1, L.uniform_w);
+    run_chain(kp_chain_, kp_steps_);
     // g = C m: the pressure-space commutator block system (control.py:1056-1067, 4625-4665)
     HIPCHK(hipStreamSynchronize(st));
     comm_.apply(m_, g_);
     HIPCHK(hipStreamSynchronize(comm_.stream));
-    for (const RowLaunch &L : mp_steps_)
-        launch_rowops(st, L.d_ops, L.nops, L.max_slices, L.R, B, 1, L.uniform_w);
+    run_chain(mp_chain_, mp_steps_);
+}
+
+// One Chebyshev chain of the pressure space: every block of a step applies the same matrix (four
+// blocks per thread share its indices and values where that form applies); the chain works on
+// fixed buffers, so it is captured once and replayed as a hipGraph (600 K_p steps of ~5 us of
+// work each: the launch gaps were two thirds of their 16 us) unless "no_graph" is set.
+void StokesPC::run_chain(Chain &c, const std::vector<RowLaunch> &steps) {
+    hipStream_t st = S_.stream;
+    const Bases B{{nullptr, nullptr, nullptr, nullptr}};
+    auto launches = [&]() {
+        for (const RowLaunch &L : steps)
+            if (!L.shared_matrix ||
+                !launch_rowops_shared(st, L.d_ops, L.nops, L.max_slices, L.R, L.uniform_w))
+                launch_rowops(st, L.d_ops, L.nops, L.max_slices, L.R, B, 1, L.uniform_w);
+    };
+    const char *ng = S_.opt("no_graph");
+    if ((ng && ng[0] == '1') || c.failed || steps.size() < 8) {
+        launches();
+        return;
+    }
+    if (!c.exec) {
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            launches();
+            e = hipStreamEndCapture(st, &c.graph);
+            if (e == hipSuccess) e = hipGraphInstantiate(&c.exec, c.graph, nullptr, nullptr, 0);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            c.exec = nullptr;
+            c.failed = true;          // plain launches of the same kernels from now on
+            launches();
+            return;
+        }
+    }
+    HIPCHK(hipGraphLaunch(c.exec, st));
 }
 
 void StokesPC::check() {
