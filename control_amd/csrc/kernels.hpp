@@ -135,7 +135,8 @@ struct TileCoarseDev {
     int32_t nc, jmax, n0max, nslots;
     int32_t nr_max;               // most restriction (= prolongation) entries of a tile
     int32_t cache_lists;          // 1: every tile copies its entries into LDS (they fit)
-    int32_t cache_einv;           // 1: ... and keeps its rows of (P^T A P)^-1 there across levels
+    int32_t cache_einv;           // 1: ... and keeps the rows of (P^T A P)^-1 it owns there
+    int32_t nown;                 // most coarse functions a tile owns: ceil(nc / ntiles)
     const int32_t *nj;            // [ntiles] number of coarse functions the own rows touch
     const int32_t *jglob;         // [ntiles][jmax] their global numbers
     const int32_t *slot0;         // [ntiles] first slot of the tile's partial sums
@@ -149,6 +150,8 @@ struct TileCoarseDev {
     const int32_t *c_slot;        // ... ascending (tile order)
     unsigned long long *cg[2];    // granule buffers of the partial sums, 2 words per slot
     uint32_t cg_bytes;
+    unsigned long long *eg[2];    // ... and of the products (E^-1 r_c)_j, 2 words per coarse function
+    uint32_t eg_bytes;
 };
 constexpr int TILE_COARSE_SLOTS = 8;   // partial-sum slots polled per thread, at most
 struct TileArgs {
@@ -179,7 +182,7 @@ int tile_sweep_max_rpt(int W, int threads);   // most row slots per thread of an
 bool tile_sweep_fuses_update(int W, int max_terms);   // update terms of any level of the run
 size_t tile_sweep_lds_bytes(int nk_pad, int its, int coarse_nc = 0, int coarse_nslots = 0,
                             int coarse_jmax = 0, int coarse_nr_max = 0,
-                            bool coarse_einv_rows = false);
+                            int coarse_einv_rows = 0);   // rows of the coarse inverse kept in LDS
 // workgroups of `threads` that are certainly co-resident (one per CU)
 int tile_sweep_max_tiles(int W, int rpt, int threads, size_t lds_bytes, int hslots,
                          bool coarse = false);

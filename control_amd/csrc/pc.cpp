@@ -382,7 +382,8 @@ bool SchurPC::prepare_tiles() {
         for (int cache = 2; cache >= 0 && !tile_coarse_ok_; --cache) {
             const size_t lds_c = tile_sweep_lds_bytes(tp.nk_pad, max_its, h_tile_coarse_.nc,
                                                       h_tile_coarse_.nslots, h_tile_coarse_.jmax,
-                                                      cache ? h_tile_coarse_.nr_max : 0, cache == 2);
+                                                      cache ? h_tile_coarse_.nr_max : 0,
+                                                      cache == 2 ? h_tile_coarse_.nown : 0);
             if (lds_c <= 150 * 1024 &&
                 tp.ntiles <= tile_sweep_max_tiles(tp.W, tp.rpt, threads, lds_c, tp.hslots, true)) {
                 tile_coarse_ok_ = true;
@@ -504,10 +505,15 @@ bool SchurPC::build_tile_coarse() {
     D.c_ip = up(c_ip);
     D.c_slot = up(c_slot);
     D.cg_bytes = (uint32_t)((size_t)nslots * 16);
+    D.eg_bytes = (uint32_t)((size_t)nc * 16);
+    D.nown = (nc + nt - 1) / nt;
     for (int i = 0; i < 2; ++i) {
         D.cg[i] = dev_alloc<unsigned long long>((size_t)nslots * 2);
         HIPCHK(hipMemset(D.cg[i], 0, D.cg_bytes));
         owned_.push_back(D.cg[i]);
+        D.eg[i] = dev_alloc<unsigned long long>((size_t)nc * 2);
+        HIPCHK(hipMemset(D.eg[i], 0, D.eg_bytes));
+        owned_.push_back(D.eg[i]);
     }
     d_tile_coarse_ = dev_upload(&D, 1);
     owned_.push_back(d_tile_coarse_);
@@ -540,7 +546,8 @@ bool SchurPC::fuse_tile_run(size_t k, size_t e, std::vector<PcStep> &out) {
                                                           h_tile_coarse_.nslots, h_tile_coarse_.jmax,
                                                           h_tile_coarse_.cache_lists
                                                               ? h_tile_coarse_.nr_max : 0,
-                                                          h_tile_coarse_.cache_einv != 0)
+                                                          h_tile_coarse_.cache_einv
+                                                              ? h_tile_coarse_.nown : 0)
                                    : tile_sweep_lds_bytes(tile_plan_.nk_pad, its);
         if (need > tile_lds_checked_) {
             if (need > 150 * 1024 ||

@@ -243,12 +243,16 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     int pe0[RPT], pe1[RPT];
     bool c_cached = true;    // the tile's P entries are in LDS (3-D: 8 per row, they stay in memory)
     int c_re0 = 0, c_pq0 = 0;
-    // this tile's rows of (P^T A P)^-1 in LDS while consecutive levels share the matrix (time-
-    // invariant operators): 12 rows of 1 089 doubles per tile and correction were 27 MB over the
-    // chip, about half of the exchange's 10 us
+    // Rows of (P^T A P)^-1: coarse function j belongs to tile j mod ntiles, which forms
+    // (E^-1 r_c)_j for everybody and publishes it as a granule (every tile holds the whole coarse
+    // residual anyway).  A tile forming the products for the functions its own rows touch read
+    // 12 rows of 1 089 doubles from L2 per correction on cfg 2 -- 27 MB over the chip, 6 of the
+    // exchange's 10 us -- four tiles each repeating the same product; the 4-5 rows a tile owns
+    // stay in LDS while consecutive levels share the matrix (time-invariant operators).
     double *EINVc = nullptr;
     bool c_einv_cache = false;
     const void *einv_key = nullptr;
+    const int c_nown = COARSE ? (c_nc > tile ? (c_nc - tile + (int)gridDim.x - 1) / (int)gridDim.x : 0) : 0;
     if constexpr (COARSE) {
         const TileCoarseDev *cd = A.coarse;
         c_cached = cd->cache_lists != 0;
@@ -885,30 +889,85 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                         RC[j] = a;
                     }
                     lds_barrier();
-                    // ---- this tile's rows of (P^T A P)^-1, a wave per coarse function
+                    // ---- the coarse functions this tile owns (j = tile, tile + ntiles, ...): a wave
+                    // per function, the product published as a granule of the same exchange number
+                    const __amdgpu_buffer_rsrc_t re_ = __builtin_amdgcn_make_buffer_rsrc(
+                        (void *)cd->eg[cepoch & 1], 0, (int)cd->eg_bytes, 0x00020000);
+                    const int ntl = (int)gridDim.x;
                     if (c_einv_cache && (const void *)einv != einv_key) {
                         // (the iterates' barrier above ordered every earlier read of EINVc)
-                        for (int k = wave; k < c_nj; k += nwaves) {
-                            const gcd_p row = einv + (size_t)JGc[k] * c_nc;
-                            for (int q = lane; q < c_nc; q += 64) EINVc[(size_t)k * c_nc + q] = row[q];
+                        for (int i = wave; i < c_nown; i += nwaves) {
+                            const gcd_p row = einv + (size_t)(tile + i * ntl) * c_nc;
+                            for (int q = lane; q < c_nc; q += 64) EINVc[(size_t)i * c_nc + q] = row[q];
                         }
                         einv_key = (const void *)einv;
                         // (a wave reads back only the row it wrote: no barrier needed)
                     }
-                    for (int k = wave; k < c_nj; k += nwaves) {
+                    for (int i = wave; i < c_nown; i += nwaves) {
                         double a = 0.0;
                         if (c_einv_cache) {
-                            const double *row = EINVc + (size_t)k * c_nc;
+                            // (reading six entries ahead of the fma chain was slower: 128 its/s
+                            // against 133 -- the 1 024-thread variant has no registers to spare)
+                            const double *row = EINVc + (size_t)i * c_nc;
                             for (int q = lane; q < c_nc; q += 64) a = __builtin_fma(row[q], RC[q], a);
                         } else {
-                            const gcd_p row = einv + (size_t)JGc[k] * c_nc;
-                            for (int q = lane; q < c_nc; q += 64) a = __builtin_fma(row[q], RC[q], a);
+                            // rows from L2: eight loads of a lane in flight before the first fma
+                            const gcd_p row = einv + (size_t)(tile + i * ntl) * c_nc;
+                            constexpr int EU = 8;
+                            for (int q0 = lane; q0 < c_nc; q0 += 64 * EU) {
+                                double rv[EU];
+#pragma unroll
+                                for (int u = 0; u < EU; ++u) {
+                                    const int q = q0 + 64 * u;
+                                    rv[u] = q < c_nc ? row[q] : 0.0;
+                                }
+#pragma unroll
+                                for (int u = 0; u < EU; ++u) {
+                                    const int q = q0 + 64 * u;
+                                    if (q < c_nc) a = __builtin_fma(rv[u], RC[q], a);
+                                }
+                            }
                         }
 #pragma unroll
                         for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-                        if (lane == 0) EC[k] = a;
+                        if (lane == 0) publish(re_, tile + i * ntl, a, cepoch);
+                    }
+                    // ---- the products for the functions the own rows touch, from their owners
+                    for (int k0 = 0; k0 < c_nj; k0 += T) {
+                        const int k = k0 + tid;
+                        u32x4 g = u32x4{0u, 0u, 0u, 0u};
+                        unsigned spins = 0;
+                        while (true) {
+                            asm volatile("" ::: "memory");
+                            bool ok = true;
+                            if (k < c_nj && (g.y != cepoch || g.w != cepoch)) {
+                                g = __builtin_amdgcn_raw_buffer_load_b128(re_, JGc[k] * 16, 0, 16);
+                                ok = g.y == cepoch && g.w == cepoch;
+                            }
+                            if (__all(ok) || dead) break;
+                            if (++spins >= TILE_SPIN_LIMIT) {
+                                dead = true;
+                                sdead = 1;
+                                atomicOr(A.err, 4u);
+                                if (atomicCAS(A.err + 1, 0u, 1u) == 0u) {
+                                    A.err[8] = (unsigned)tile;
+                                    A.err[9] = cepoch;
+                                    A.err[10] = 0xfffeu;            // products of a coarse exchange
+                                    A.err[11] = (unsigned)(k < c_nj ? JGc[k] : 0);
+                                    A.err[12] = g.y;
+                                    A.err[13] = g.w;
+                                    A.err[16] = 2u;
+                                }
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        if (k < c_nj)
+                            EC[k] = __longlong_as_double((long long)(
+                                (unsigned long long)g.x | ((unsigned long long)g.z << 32)));
                     }
                     lds_barrier();
+                    dead = sdead != 0;
                     // ---- prolongation onto the own rows of the current iterate
                     double *Xc = X + cur * nkp;
 #pragma unroll
@@ -1209,11 +1268,11 @@ bool tile_sweep_fuses_update(int W, int max_terms) {
 }
 
 size_t tile_sweep_lds_bytes(int nk_pad, int its, int coarse_nc, int coarse_nslots, int coarse_jmax,
-                            int coarse_nr_max, bool coarse_einv_rows) {
-    if (coarse_nc > 0 && coarse_einv_rows)
+                            int coarse_nr_max, int coarse_einv_rows) {
+    if (coarse_nc > 0 && coarse_einv_rows > 0)
         return tile_sweep_lds_bytes(nk_pad, its, coarse_nc, coarse_nslots, coarse_jmax,
-                                    coarse_nr_max, false) +
-               (size_t)coarse_jmax * coarse_nc * sizeof(double) + 8;
+                                    coarse_nr_max, 0) +
+               (size_t)coarse_einv_rows * coarse_nc * sizeof(double) + 8;
     if (coarse_nc > 0)
         return (2 * (size_t)nk_pad + 3 * (size_t)std::max(1, its) + 1 + (size_t)coarse_nslots +
                 (size_t)coarse_nc + (size_t)coarse_jmax + 2 * (size_t)coarse_nr_max) * sizeof(double) +
@@ -1280,13 +1339,16 @@ void launch_tile_sweep(hipStream_t s, const TileArgs &a, const TileLevel *d_leve
             launch_zero_bytes(s, a.gold[i], granule_words * sizeof(unsigned long long));
         }
         if (h_coarse)
-            for (int i = 0; i < 2; ++i) launch_zero_bytes(s, h_coarse->cg[i], h_coarse->cg_bytes);
+            for (int i = 0; i < 2; ++i) {
+                launch_zero_bytes(s, h_coarse->cg[i], h_coarse->cg_bytes);
+                launch_zero_bytes(s, h_coarse->eg[i], h_coarse->eg_bytes);
+            }
         chk(hipGetLastError(), "clearing the granule buffers");
     }
     const size_t lds = h_coarse ? tile_sweep_lds_bytes(a.nk_pad, a.its, h_coarse->nc,
                                                        h_coarse->nslots, h_coarse->jmax,
                                                        h_coarse->cache_lists ? h_coarse->nr_max : 0,
-                                                       h_coarse->cache_einv != 0)
+                                                       h_coarse->cache_einv ? h_coarse->nown : 0)
                                 : tile_sweep_lds_bytes(a.nk_pad, a.its);
     tile_fn f = pick_tile(a.W, a.rpt, threads, a.fused_update != 0, a.hslots, h_coarse != nullptr);
     if (!f) throw TileLaunchError{"tile sweep program: no kernel variant for this plan"};
