@@ -29,10 +29,11 @@ ap.add_argument("--tiles", type=int, default=16, help="tiles per axis")
 ap.add_argument("--dim", type=int, default=2)
 ap.add_argument("--max-it", type=int, default=120)
 ap.add_argument("--variants", default="")
+ap.add_argument("--T", type=float, default=2.0)
 a = ap.parse_args()
 
 p = common.heat_problem(space="p1" if a.dim == 2 else "p1_3d", n=a.n, n_t=a.n_t, beta=a.beta,
-                        T=2.0, CN=False, share=True)
+                        T=a.T, CN=False, share=True)
 sd, m, tau = p["sd"], p["m"], p["tau"]
 nodes = p["nodes"]
 nx = sd.n_dofs
