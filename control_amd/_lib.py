@@ -44,7 +44,9 @@ class PcStokesDesc(C.Structure):
                 ("kp_indptr", c_i32p), ("kp_indices", c_i32p), ("kp_values", c_f64p),
                 ("mp_indptr", c_i32p), ("mp_indices", c_i32p), ("mp_values", c_f64p),
                 ("kp_its", C.c_int), ("kp_emin", C.c_double), ("kp_emax", C.c_double),
-                ("mp_its", C.c_int), ("mp_emin", C.c_double), ("mp_emax", C.c_double)]
+                ("mp_its", C.c_int), ("mp_emin", C.c_double), ("mp_emax", C.c_double),
+                ("kp_coarse_cycles", C.c_int), ("kp_n_coarse", C.c_int64),
+                ("kp_p_indptr", c_i32p), ("kp_p_indices", c_i32p), ("kp_p_values", c_f64p)]
 
 
 class Info(C.Structure):

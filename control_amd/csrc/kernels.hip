@@ -1813,6 +1813,14 @@ __global__ void fill_kernel(double *__restrict__ y, double v, int64_t n) {
          p += (int64_t)gridDim.x * blockDim.x)
         y[p] = v;
 }
+__global__ void add_constant_kernel(double *__restrict__ y, double v, int64_t n) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n;
+         p += (int64_t)gridDim.x * blockDim.x)
+        y[p] += v;
+}
+void launch_add_constant(hipStream_t s, double *y, double v, int64_t n) {
+    hipLaunchKernelGGL(add_constant_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, v, n);
+}
 // (sizes are multiples of 4 bytes: flag words and 8-byte granule halves)
 __global__ void zero_words_kernel(unsigned *__restrict__ p, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;

@@ -247,6 +247,7 @@ void launch_mdot(hipStream_t s, const double *w, VecList V, int nv, int64_t n,
 // out[0] = sqrt(<w, w> + extra) where extra = (add ? *add : 0)
 void launch_norm2_finish(hipStream_t s, const double *dot, double *out);
 void launch_zero_bytes(hipStream_t s, void *p, size_t nbytes);   // kernel node, not a memset node
+void launch_add_constant(hipStream_t s, double *y, double v, int64_t n);   // y[i] += v
 
 // ---- coarse space of the two-grid sub-solves on the device: P by rows (prolongation) and by
 // columns (restriction), scratch for one correction

@@ -302,17 +302,32 @@ class StokesPC : public PcBase {
     double *P_[3] = {nullptr, nullptr, nullptr};
     double *halo_a_ = nullptr, *halo_b_ = nullptr;   // CN on time shards: neighbour blocks of the T scans
     std::vector<void *> owned_;
-    std::vector<RowLaunch> lin_, kp_steps_, mp_steps_;
+    // a step of a pressure-space chain: a batched row launch, or -- two-grid K_p solve -- the
+    // Galerkin correction x_out = x_in + P E^-1 P^T r of every block
+    struct ChainStep {
+        RowLaunch L;
+        bool coarse = false;
+        const double *r = nullptr, *x_in = nullptr;
+        double *x_out = nullptr;
+    };
+    std::vector<RowLaunch> lin_;
+    std::vector<ChainStep> kp_steps_, mp_steps_;
     // the two Chebyshev chains (hundreds of small launches on fixed buffers) replayed as graphs
     struct Chain {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         bool failed = false;
     } kp_chain_, mp_chain_;
-    void run_chain(Chain &c, const std::vector<RowLaunch> &steps);
+    void run_chain(Chain &c, const std::vector<ChainStep> &steps);
+    // two-grid K_p solve
+    CoarseDev kp_coarse_;
+    double *kp_einv_ = nullptr, *kp_r_ = nullptr, *kp_x0_ = nullptr;
+    int kp_cycles_ = 0;
+    void build_kp_coarse(const kkt_pc_stokes_desc &d);
+    void emit_kp_two_grid(int its, double emin, double emax, const double *b, double *out);
     DevMat upload(int64_t nrows, int64_t ncols, const int32_t *ip, const int32_t *ix,
                   const double *v, bool want_dinv);
-    void emit_cheb(std::vector<RowLaunch> &dst, const DevMat &A, int its, double emin, double emax,
+    void emit_cheb(std::vector<ChainStep> &dst, const DevMat &A, int its, double emin, double emax,
                    const double *b, double *out);
 };
 

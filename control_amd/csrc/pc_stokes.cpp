@@ -62,7 +62,7 @@ StokesPC::DevMat StokesPC::upload(int64_t nrows, int64_t ncols, const int32_t *i
 }
 
 // KSPSolve_Chebyshev + PCJACOBI on all 2n pressure blocks in lock step (its == 0: Jacobi)
-void StokesPC::emit_cheb(std::vector<RowLaunch> &dst, const DevMat &A, int its, double emin,
+void StokesPC::emit_cheb(std::vector<ChainStep> &dst, const DevMat &A, int its, double emin,
                          double emax, const double *b, double *out) {
     const Pattern &P = S_.patterns[A.pat];
     const int nb = 2 * n_;
@@ -84,7 +84,7 @@ void StokesPC::emit_cheb(std::vector<RowLaunch> &dst, const DevMat &A, int its, 
         op.c3 = scale;
         ops[k] = op;
     }
-    dst.push_back(upload_launch(P, ops));
+    dst.push_back(ChainStep{upload_launch(P, ops)});
     if (its <= 1) return;
     const double alpha = 1.0 - scale * emin, mu = 1.0 / alpha, omegaprod = 2.0 / alpha;
     double c_km1 = 1.0, c_k = mu;
@@ -107,9 +107,184 @@ void StokesPC::emit_cheb(std::vector<RowLaunch> &dst, const DevMat &A, int its, 
             op.c3 = scale * omega;
             ops[k] = op;
         }
-        dst.push_back(upload_launch(P, ops));
+        dst.push_back(ChainStep{upload_launch(P, ops)});
         c_km1 = c_k;
         c_k = c_kp1;
+    }
+}
+
+// ---- two-grid K_p solve (kkt_pc_stokes_desc.kp_coarse_*)
+//
+// K_p is a Neumann Laplacian: kappa of its Jacobi-scaled non-zero spectrum grows like h^-2 (1.3e4 on
+// the 129^2 pressure grid of BASELINE configs[2]) and the outer iteration is sensitive to this
+// solve -- 600 plain sweeps, each a 16 us launch, were the best plain setting.  Here: cycles x
+// [x += P E^-1 P^T (b - K_p x) for every block; `its` sweeps on [emin, emax] from x].  The Galerkin
+// matrix E = P^T K_p P inherits the constants as its kernel (the columns of P sum to one on every
+// row), so E + (trace E / n_c^2) 1 1^T is inverted instead: on right-hand sides orthogonal to the
+// constants -- P^T r of a residual in the range of K_p -- it acts as the pseudo-inverse.
+void StokesPC::build_kp_coarse(const kkt_pc_stokes_desc &d) {
+    const int nc = (int)d.kp_n_coarse;
+    if (nc < 1 || !d.kp_p_indptr || !d.kp_p_indices || !d.kp_p_values)
+        fail(KKT_ERR_ARG, "kkt_set_pc_stokes: coarse space of the K_p solve missing");
+    hipStream_t st = S_.stream;
+    std::vector<int32_t> ip(d.kp_p_indptr, d.kp_p_indptr + np_ + 1);
+    if (ip[0] != 0) fail(KKT_ERR_ARG, "kp_p_indptr must start at 0");
+    const int64_t nnz = ip[np_];
+    std::vector<int32_t> ix(d.kp_p_indices, d.kp_p_indices + nnz);
+    std::vector<double> pv(d.kp_p_values, d.kp_p_values + nnz);
+    for (int32_t c : ix)
+        if (c < 0 || c >= nc) fail(KKT_ERR_ARG, "kp_p_indices out of range");
+    // P^T by a counting sort (entries of a column in ascending row order: the restriction's order)
+    std::vector<int32_t> tip(nc + 1, 0), tix(nnz);
+    std::vector<double> tv(nnz);
+    for (int32_t c : ix) tip[c + 1]++;
+    for (int j = 0; j < nc; ++j) tip[j + 1] += tip[j];
+    {
+        std::vector<int32_t> cur(tip.begin(), tip.end() - 1);
+        for (int64_t r = 0; r < np_; ++r)
+            for (int32_t q = ip[r]; q < ip[r + 1]; ++q) {
+                const int32_t at = cur[ix[q]]++;
+                tix[at] = (int32_t)r;
+                tv[at] = pv[q];
+            }
+    }
+    auto up = [&](const auto &v) {
+        auto *p = dev_upload(v.data(), std::max<size_t>(1, v.size()));
+        owned_.push_back((void *)p);
+        return p;
+    };
+    CoarseDev &c = kp_coarse_;
+    c.nc = nc;
+    c.p_ip = up(ip);
+    c.p_ix = up(ix);
+    c.p_v = up(pv);
+    c.pt_ip = up(tip);
+    c.pt_ix = up(tix);
+    c.pt_v = up(tv);
+    c.rc = dev_alloc<double>(nc);
+    c.ec = dev_alloc<double>(nc);
+    owned_.push_back(c.rc);
+    owned_.push_back(c.ec);
+    // E column by column with the kernels the sweeps use (fixed summation orders)
+    const Pattern &P = S_.patterns[Kp_.pat];
+    double *x = dev_alloc<double>(np_ + 32), *y = dev_alloc<double>(np_ + 32);
+    double *E = dev_alloc<double>((size_t)nc * nc);
+    RowOp op = base_op(P);
+    op.mode = EPI_LIN;
+    op.nterms = 1;
+    op.t[0].vals = Kp_.vals;
+    op.t[0].x = vabs(x);
+    op.y = vabs(y);
+    op.ca = 1.0;
+    RowOp *d_op = dev_upload(&op, 1);
+    const Bases B{{nullptr, nullptr, nullptr, nullptr}};
+    for (int k = 0; k < nc; ++k) {
+        launch_coarse_column(st, c, k, x, np_);
+        launch_rowops(st, d_op, 1, P.nslices, P.R, B, 1, P.uniform_w);
+        launch_coarse_restrict(st, c, y, E + k, nc);        // column k of the row-major E
+    }
+    // deflation of the constants: every entry + trace(E) / n_c^2 (diagonal summed on the host in
+    // index order)
+    {
+        std::vector<double> diag(nc);
+        HIPCHK(hipMemcpy2DAsync(diag.data(), sizeof(double), E, ((size_t)nc + 1) * sizeof(double),
+                                sizeof(double), nc, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        double tr = 0.0;
+        for (double v : diag) tr += v;
+        launch_add_constant(st, E, tr / ((double)nc * (double)nc), (int64_t)nc * nc);
+    }
+    kp_einv_ = dev_alloc<double>((size_t)nc * nc);
+    owned_.push_back(kp_einv_);
+    int *d_piv = dev_alloc<int>(1);
+    double *d_colbuf = dev_alloc<double>(nc + 1);
+    unsigned *d_flag = dev_alloc<unsigned>(1);
+    HIPCHK(hipMemsetAsync(d_flag, 0, sizeof(unsigned), st));
+    launch_dense_inverse(st, E, kp_einv_, nc, d_piv, d_colbuf, d_flag);
+    unsigned singular = 0;
+    HIPCHK(hipMemcpyAsync(&singular, d_flag, sizeof singular, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (void *q : {(void *)x, (void *)y, (void *)E, (void *)d_op, (void *)d_piv, (void *)d_colbuf,
+                    (void *)d_flag})
+        (void)hipFree(q);
+    if (singular)
+        fail(KKT_ERR_STATE, "coarse matrix of the K_p solve is singular beyond the constants "
+                            "(dependent coarse functions?)");
+}
+
+void StokesPC::emit_kp_two_grid(int its, double emin, double emax, const double *b, double *out) {
+    const Pattern &P = S_.patterns[Kp_.pat];
+    const int nb = 2 * n_;
+    auto blk = [&](const double *base, int k) { return base + (int64_t)k * np_; };
+    const double scale = 2.0 / (emax + emin);
+    // coefficients of the sweeps 2 .. its (the recurrence of emit_cheb)
+    std::vector<double> c1(its + 1, 0.0), c2(its + 1, 1.0), c3(its + 1, scale);
+    {
+        const double alpha = 1.0 - scale * emin, mu = 1.0 / alpha, omegaprod = 2.0 / alpha;
+        double c_km1 = 1.0, c_k = mu;
+        for (int step = 2; step <= its; ++step) {
+            const double c_kp1 = 2.0 * mu * c_k - c_km1;
+            const double omega = omegaprod * c_k / c_kp1;
+            c1[step] = 1.0 - omega;
+            c2[step] = omega;
+            c3[step] = scale * omega;
+            c_km1 = c_k;
+            c_k = c_kp1;
+        }
+    }
+    const double *xcur = nullptr;
+    for (int cyc = 0; cyc < kp_cycles_; ++cyc) {
+        const bool last_cycle = cyc + 1 == kp_cycles_;
+        const double *r = b;
+        if (cyc > 0) {          // r = b - K_p x
+            std::vector<RowOp> ops(nb);
+            for (int k = 0; k < nb; ++k) {
+                RowOp op = base_op(P);
+                op.mode = EPI_LIN;
+                op.nterms = 1;
+                op.t[0].vals = Kp_.vals;
+                op.t[0].x = vabs(blk(xcur, k));
+                op.y = vabs(blk(kp_r_, k));
+                op.ca = -1.0;
+                op.cz = 1.0;
+                op.z = vabs(blk(b, k));
+                ops[k] = op;
+            }
+            kp_steps_.push_back(ChainStep{upload_launch(P, ops)});
+            r = kp_r_;
+        }
+        ChainStep cs;
+        cs.coarse = true;
+        cs.r = r;
+        cs.x_in = xcur;
+        cs.x_out = kp_x0_;
+        kp_steps_.push_back(cs);
+        auto target = [&](int step) -> double * {
+            return (last_cycle && step == its) ? out : P_[(step - 1) % 3];
+        };
+        for (int step = 1; step <= its; ++step) {
+            const double *pk = step == 1 ? kp_x0_ : target(step - 1);
+            const double *pkm1 = step == 1 ? nullptr : (step == 2 ? kp_x0_ : target(step - 2));
+            std::vector<RowOp> ops(nb);
+            for (int k = 0; k < nb; ++k) {
+                RowOp op = base_op(P);
+                op.mode = EPI_CHEB;
+                op.nterms = 1;
+                op.t[0].vals = Kp_.vals;
+                op.t[0].x = vabs(blk(pk, k));
+                op.y = vabs(blk(target(step), k));
+                op.b = vabs(blk(b, k));
+                op.pk = vabs(blk(pk, k));
+                op.pkm1 = vabs(pkm1 ? blk(pkm1, k) : nullptr);
+                op.dinv = Kp_.dinv;
+                op.c1 = step == 1 ? 0.0 : c1[step];
+                op.c2 = step == 1 ? 1.0 : c2[step];
+                op.c3 = step == 1 ? scale : c3[step];
+                ops[k] = op;
+            }
+            kp_steps_.push_back(ChainStep{upload_launch(P, ops)});
+        }
+        xcur = target(its);
     }
 }
 
@@ -227,7 +402,18 @@ StokesPC::StokesPC(System &outer, System &inner, System &commutator, const kkt_p
         }
     }
     kp_its_ = kp_its;
-    emit_cheb(kp_steps_, Kp_, kp_its, kp_emin, kp_emax, h_, m_);
+    kp_cycles_ = d.kp_coarse_cycles;
+    if (kp_cycles_ < 0) fail(KKT_ERR_ARG, "negative number of coarse cycles for K_p");
+    if (kp_cycles_ > 0) {
+        if (kp_its < 1 || !(kp_emin > 0.0) || !(kp_emax > kp_emin))
+            fail(KKT_ERR_ARG, "two-grid K_p solve needs kp_its >= 1 and 0 < kp_emin < kp_emax");
+        build_kp_coarse(d);
+        kp_r_ = vec(n1);
+        kp_x0_ = vec(n1);
+        emit_kp_two_grid(kp_its, kp_emin, kp_emax, h_, m_);
+    } else {
+        emit_cheb(kp_steps_, Kp_, kp_its, kp_emin, kp_emax, h_, m_);
+    }
     emit_cheb(mp_steps_, Mp_, d.mp_its, d.mp_emin, d.mp_emax, g_, out_ + n0);
     HIPCHK(hipStreamSynchronize(S_.stream));
 }
@@ -237,9 +423,11 @@ StokesPC::~StokesPC() {
         if (c->exec) (void)hipGraphExecDestroy(c->exec);
         if (c->graph) (void)hipGraphDestroy(c->graph);
     }
-    for (auto *v : {&lin_, &kp_steps_, &mp_steps_})
-        for (auto &L : *v)
-            if (L.d_ops) (void)hipFree(L.d_ops);
+    for (auto &L : lin_)
+        if (L.d_ops) (void)hipFree(L.d_ops);
+    for (auto *v : {&kp_steps_, &mp_steps_})
+        for (auto &c : *v)
+            if (c.L.d_ops) (void)hipFree(c.L.d_ops);
     for (void *p : owned_)
         if (p) (void)hipFree(p);
 }
@@ -295,14 +483,23 @@ void StokesPC::run() {
 // blocks per thread share its indices and values where that form applies); the chain works on
 // fixed buffers, so it is captured once and replayed as a hipGraph (600 K_p steps of ~5 us of
 // work each: the launch gaps were two thirds of their 16 us) unless "no_graph" is set.
-void StokesPC::run_chain(Chain &c, const std::vector<RowLaunch> &steps) {
+void StokesPC::run_chain(Chain &c, const std::vector<ChainStep> &steps) {
     hipStream_t st = S_.stream;
     const Bases B{{nullptr, nullptr, nullptr, nullptr}};
     auto launches = [&]() {
-        for (const RowLaunch &L : steps)
+        for (const ChainStep &cs : steps) {
+            if (cs.coarse) {
+                for (int k = 0; k < 2 * n_; ++k)
+                    launch_coarse_correction(st, kp_coarse_, kp_einv_, cs.r + (int64_t)k * np_,
+                                             cs.x_in ? cs.x_in + (int64_t)k * np_ : nullptr,
+                                             cs.x_out + (int64_t)k * np_, np_);
+                continue;
+            }
+            const RowLaunch &L = cs.L;
             if (!L.shared_matrix ||
                 !launch_rowops_shared(st, L.d_ops, L.nops, L.max_slices, L.R, L.uniform_w))
                 launch_rowops(st, L.d_ops, L.nops, L.max_slices, L.R, B, 1, L.uniform_w);
+        }
     };
     const char *ng = S_.opt("no_graph");
     if ((ng && ng[0] == '1') || c.failed || steps.size() < 8) {

@@ -436,6 +436,14 @@ class MultiBlockSystem:
                 setattr(d, name + "_indptr", ip.ctypes.data_as(_lib.c_i32p))
                 setattr(d, name + "_indices", ix.ctypes.data_as(_lib.c_i32p))
                 setattr(d, name + "_values", va.ctypes.data_as(_lib.c_f64p))
+            kpc = getattr(pc_fn.kp, "coarse", None)
+            if kpc is not None:      # two-grid K_p solve (constants deflated in the library)
+                kp_ip, kp_ix, kp_v = _as_csr(kpc.P)
+                d.kp_coarse_cycles = int(kpc.cycles)
+                d.kp_n_coarse = int(kpc.P.shape[1])
+                d.kp_p_indptr = kp_ip.ctypes.data_as(_lib.c_i32p)
+                d.kp_p_indices = kp_ix.ctypes.data_as(_lib.c_i32p)
+                d.kp_p_values = kp_v.ctypes.data_as(_lib.c_f64p)
             self._ck(self._lib.kkt_set_pc_stokes(self._h, inner._h, comm._h, C.byref(d)))
             self._pc_state = pc_fn          # keeps inner and commutator alive
         elif callable(pc_fn):

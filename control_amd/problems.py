@@ -71,7 +71,8 @@ def stokes_problem(n=4, n_t=4, beta=1.0e-2, T=2.0, CN=False, share=True):
     return dict(th=th, tau=tau, beta=beta, n_t=n_t, CN=CN, m=bl["m"], blocks=bl)
 
 
-def stokes_gpu(p, specs=STOKES_SPECS, options=None, comm=None, device=0, coarse=None):
+def stokes_gpu(p, specs=STOKES_SPECS, options=None, comm=None, device=0, coarse=None,
+               kp_coarse=None):
     """Outer system, velocity KKT system and pressure commutator on the GPU + the StokesPC."""
     from .multiblock import (ChebSpec, CoarseSpace, ConstantNullspace, DirichletBCNullspace,
                              MultiBlockSystem, SchurPC, StokesPC)
@@ -99,8 +100,11 @@ def stokes_gpu(p, specs=STOKES_SPECS, options=None, comm=None, device=0, coarse=
     inner_pc = SchurPC(kind="CN" if CN else "BE", M=th.M_v, beta=p["beta"],
                        bc_nodes=th.boundary_v, mass=ChebSpec(*specs["mass"]),
                        schur=schur, n_t=p["n_t"], tau=p["tau"])
+    kp = ChebSpec(*specs["kp"])
+    if kp_coarse is not None:   # (P_p, cycles): two-grid form of the pressure-Laplacian solve
+        kp.coarse = CoarseSpace(kp_coarse[0], int(kp_coarse[1]))
     gpc = StokesPC(inner=inner, inner_pc=inner_pc, commutator=commutator, B=th.B, K_p=th.K_p,
-                   M_p=th.M_p, kp=ChebSpec(*specs["kp"]), mp=ChebSpec(*specs["mp"]),
+                   M_p=th.M_p, kp=kp, mp=ChebSpec(*specs["mp"]),
                    n_p_blocks=m, b_scale=p["tau"], post_scale=1.0 / p["tau"]**2, cn=CN)
     return outer, gpc
 

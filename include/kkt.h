@@ -238,6 +238,15 @@ typedef struct kkt_pc_stokes_desc {
                                 from K_p, constants deflated) */
     int mp_its;              /* control.py:957-971: 20 (0: one Jacobi application, :973-979) */
     double mp_emin, mp_emax;
+    /* Two-grid form of the K_p solve (0 cycles: the plain polynomial above): kp_coarse_cycles x
+     * [Galerkin correction on the coarse space P_p (np x kp_n_coarse, CSR; its columns must sum to
+     * the constant vector, which K_p annihilates: the Galerkin matrix is inverted with the
+     * constants deflated, E + (trace E / n_c^2) 1 1^T); kp_its sweeps on [kp_emin, kp_emax] from
+     * the corrected iterate].  Needs kp_its >= 1 and explicit bounds. */
+    int kp_coarse_cycles;
+    int64_t kp_n_coarse;
+    const int32_t *kp_p_indptr, *kp_p_indices;
+    const double *kp_p_values;
 } kkt_pc_stokes_desc;
 int kkt_set_pc_stokes(kkt_handle h, kkt_handle inner, kkt_handle commutator,
                       const kkt_pc_stokes_desc *desc);

@@ -532,6 +532,9 @@ class CoarseSpace:
     on ``[emin, emax]`` (the upper part of the spectrum: what the coarse space does not see)."""
     P: object
     cycles: int = 1
+    # the sub-solve matrix annihilates the constants (the pressure Laplacian K_p) and the columns of
+    # P sum to the constant vector: invert E + (trace E / n_c^2) 1 1^T instead of the singular E
+    deflate: bool = False
 
 
 def coarse_chebyshev(A, dinv, b, spec, Einv):
@@ -547,9 +550,14 @@ def coarse_chebyshev(A, dinv, b, spec, Einv):
 
 
 def coarse_inverse(At, coarse):
-    """``(P^T A P)^-1`` of the bc-assembled sub-solve matrix (dense)."""
+    """``(P^T A P)^-1`` of the bc-assembled sub-solve matrix (dense); with ``coarse.deflate`` the
+    inverse of ``E + (trace E / n_c^2) 1 1^T``, which acts as the pseudo-inverse of the singular
+    ``E`` on right-hand sides orthogonal to the constants."""
     P = coarse.P
-    return np.linalg.inv((P.T @ (At @ P)).toarray())
+    E = (P.T @ (At @ P)).toarray()
+    if getattr(coarse, "deflate", False):
+        E = E + np.trace(E) / float(E.shape[0]) ** 2
+    return np.linalg.inv(E)
 
 
 # ----------------------------------------------------------------------- the system
@@ -759,8 +767,12 @@ class ChebSpec:
 def _inner_solve(At, spec, rhs, Einv=None):
     dinv = 1.0 / At.diagonal()
     if getattr(spec, "coarse", None) is not None:
-        return coarse_chebyshev(At, dinv, rhs, spec, coarse_inverse(At, spec.coarse)
-                                if Einv is None else Einv)
+        if Einv is None:       # (one inverse per matrix: kept on the specification)
+            cache = spec.__dict__.setdefault("_einv_cache", {})
+            if id(At) not in cache:
+                cache[id(At)] = (At, coarse_inverse(At, spec.coarse))
+            Einv = cache[id(At)][1]
+        return coarse_chebyshev(At, dinv, rhs, spec, Einv)
     if spec.its == 0:
         return dinv * rhs
     return chebyshev_jacobi(At, dinv, rhs, spec.emin, spec.emax, spec.its, spec.eimag)

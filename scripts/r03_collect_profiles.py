@@ -29,7 +29,8 @@ def last_json(path):
 
 
 for name in ("bench_r03.json", "bench_under_rocprof.json", "other_configs.jsonl",
-             "bench_stokes2d.json", "bench_stokes2d_round2_pc.json", "tts_quality.txt"):
+             "bench_stokes2d.json", "bench_stokes2d_round2_pc.json", "bench_stokes2d_plain_kp.json",
+             "tts_quality.txt"):
     if os.path.exists(os.path.join(SRC, name)):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, name))
 for kind in ("kernel_stats", "domain_stats"):

@@ -42,7 +42,10 @@ done
 timeout -k 10 400 python bench.py --workload stokes2d --steps 10 --warmup 2 > $o/bench_stokes2d.json 2> $o/stokes.err
 echo "stokes rc=$?"
 # the round-2 preconditioner of this leg (plain polynomials of 40 sweeps): faster per iteration, does not converge
-timeout -k 10 400 python bench.py --workload stokes2d --steps 10 --warmup 2 --coarse-cycles 0 --schur-its 40 --schur-emin 0.002 --kp-its 40 --kp-emin 0.002 --tts-max-it 200 > $o/bench_stokes2d_round2_pc.json 2>> $o/stokes.err
+timeout -k 10 400 python bench.py --workload stokes2d --steps 10 --warmup 2 --coarse-cycles 0 --schur-its 40 --schur-emin 0.002 --kp-coarse-cycles 0 --kp-its 40 --kp-emin 0.002 --tts-max-it 200 > $o/bench_stokes2d_round2_pc.json 2>> $o/stokes.err
 echo "stokes round-2 pc rc=$?"
+# plain 600-sweep pressure-Laplacian polynomial (the default before its two-grid form)
+timeout -k 10 400 python bench.py --workload stokes2d --steps 10 --warmup 2 --kp-coarse-cycles 0 > $o/bench_stokes2d_plain_kp.json 2>> $o/stokes.err
+echo "stokes plain kp rc=$?"
 python3 scripts/r03_tts_quality.py > $o/tts_quality.txt 2>&1
 ls $o

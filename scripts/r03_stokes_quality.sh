@@ -7,10 +7,20 @@ mkdir -p $o
 : > $o/lines.jsonl
 run() {
   echo "== $*" >> $o/err.log
-  timeout -k 10 330 python bench.py --workload stokes2d --steps 10 --warmup 2 "$@" >> $o/lines.jsonl 2>> $o/err.log
+  # (base flags: what bench.py's defaults were when the first three groups ran -- plain K_p
+  # polynomial, estimated unless --kp-its is given, lower bound 2e-3 unless --kp-emin is given)
+  timeout -k 10 330 python bench.py --workload stokes2d --steps 10 --warmup 2 --kp-coarse-cycles 0 --kp-its -1 --kp-emin 0.002 "$@" >> $o/lines.jsonl 2>> $o/err.log
   echo "[$*] rc=$?"
 }
-if [ "$1" = "third" ]; then
+if [ "$1" = "fourth" ]; then      # two-grid form of the K_p solve
+run --kp-coarse-cycles 2 --kp-its 8 --kp-emin 0.07
+run --kp-coarse-cycles 3 --kp-its 8 --kp-emin 0.07
+run --kp-coarse-cycles 2 --kp-its 12 --kp-emin 0.05
+run --kp-coarse-cycles 3 --kp-its 16 --kp-emin 0.05
+run --kp-coarse-cycles 2 --kp-its 20 --kp-emin 0.03
+run --kp-coarse-cycles 2 --kp-its 12 --kp-emin 0.05 --kp-coarse-cell 2
+run --kp-coarse-cycles 4 --kp-its 12 --kp-emin 0.05
+elif [ "$1" = "third" ]; then
 run --coarse-cycles 3 --coarse-cell 8 --kp-its 300 --kp-emin 0.0005
 run --coarse-cycles 2 --coarse-cell 8 --kp-its 600 --kp-emin 0.0002
 run --coarse-cycles 2 --coarse-cell 8 --schur-its 12 --schur-emin 0.07 --kp-its 300 --kp-emin 0.0005
@@ -23,7 +33,7 @@ run --coarse-cycles 2 --coarse-cell 16 --kp-its 160
 run --coarse-cycles 3 --coarse-cell 8 --kp-its 160
 else
 run
-run --schur-its 80 --schur-emin 0.002 --kp-its 80
+run --schur-its 80 --schur-emin 0.002 --kp-its 80 --kp-coarse-cycles 0
 run --schur-its 160 --schur-emin 0.002 --kp-its 160
 run --coarse-cycles 2 --coarse-cell 8
 run --coarse-cycles 3 --coarse-cell 8

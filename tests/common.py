@@ -33,7 +33,7 @@ def rel_err(a, b):
 
 
 
-def stokes_oracle(p, specs=STOKES_SPECS, coarse=None):
+def stokes_oracle(p, specs=STOKES_SPECS, coarse=None, kp_coarse=None):
     from oracle import kkt_oracle as ko
     th, m, CN, bl = p["th"], p["m"], p["CN"], p["blocks"]
     kw = dict(sub_n_blocks_00_0=m, sub_n_blocks_11_0=m) if CN else {}
@@ -45,10 +45,13 @@ def stokes_oracle(p, specs=STOKES_SPECS, coarse=None):
     schur = ko.ChebSpec(*specs["schur"])
     if coarse is not None:
         schur.coarse = ko.CoarseSpace(coarse[0], int(coarse[1]))
+    kp = ko.ChebSpec(*specs["kp"])
+    if kp_coarse is not None:      # two-grid K_p solve, constants deflated
+        kp.coarse = ko.CoarseSpace(kp_coarse[0], int(kp_coarse[1]), deflate=True)
     opc = ko.pc_instationary_incompressible(
         th.M_v, bl["inner"], th.B, th.M_p, th.K_p, bl["commutator"], p["n_t"], p["tau"],
         p["beta"], th.boundary_v, ko.ChebSpec(*specs["mass"]), schur,
-        ko.ChebSpec(*specs["kp"]), ko.ChebSpec(*specs["mp"]), CN=CN)
+        kp, ko.ChebSpec(*specs["mp"]), CN=CN)
     return osys, opc
 
 

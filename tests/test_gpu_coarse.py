@@ -80,6 +80,35 @@ def test_stokes_velocity_sub_solves_in_two_grid_form(CN):
     assert common.rel_err(outer.pc_apply(x, gpc), osys.pc_apply(opc, x)) < (1e-7 if CN else 1e-4)
 
 
+@pytest.mark.parametrize("CN", [False, True])
+def test_stokes_pressure_laplacian_solve_in_two_grid_form(CN):
+    """The K_p solve of the StokesPC as 2 x [Galerkin correction with the constants deflated,
+    6 sweeps] (kkt_pc_stokes_desc.kp_coarse_*): one application against the oracle, and a solve
+    of a manufactured right-hand side."""
+    p = common.stokes_problem(n=8, n_t=5 if CN else 4, CN=CN)
+    th, m = p["th"], p["m"]
+    Pp = multilinear_coarse_space(th.coords_p, (), cells=3)
+    assert Pp.shape == (th.n_p, 16)
+    assert np.allclose(np.asarray(Pp.sum(axis=1)).ravel(), 1.0)      # partition of unity
+    specs = dict(common.STOKES_SPECS, kp=(6, 0.15, 2.1))
+    osys, opc = common.stokes_oracle(p, specs, kp_coarse=(Pp, 2))
+    outer, gpc = common.stokes_gpu(p, specs, kp_coarse=(Pp, 2))
+    x = common.rng_vector(osys.N)
+    assert common.rel_err(outer.pc_apply(x, gpc), osys.pc_apply(opc, x)) < (1e-7 if CN else 1e-4)
+    rng = np.random.default_rng(common.SEED)
+    x0 = rng.standard_normal((2 * m, th.n_v))
+    x0[:, th.boundary_v] = 0.0
+    x1 = rng.standard_normal((2 * m, th.n_p))
+    x1 -= x1.mean(axis=1, keepdims=True)
+    b0, b1 = osys.split(osys.mult(osys.join(x0, x1)))
+    u0, u1 = np.zeros_like(x0), np.zeros_like(x1)
+    res = outer.solve(u0, u1, b0, b1, pc_fn=gpc, solver_parameters={
+        "linear_solver": "fgmres", "maximum_iterations": 200, "relative_tolerance": 1.0e-10,
+        "absolute_tolerance": 1.0e-30, "monitor_convergence": False})
+    assert res.reason > 0
+    assert np.abs(u0 - x0).max() < 1.0e-6
+
+
 def test_coarse_tile_program_soak_and_sharded_equivalents():
     """The tile program with coarse corrections, repeated: every application equals the first bit
     for bit (the coarse residual is summed in a fixed order) and the plain launches to round-off
