@@ -51,3 +51,32 @@ def test_outer_block_layout():
     assert abs(b10[(1, 1)] - p["tau"] * th.B).max() == 0.0
     assert abs(b01[(2 * m - 1, 2 * m - 1)] - p["tau"] * th.B.T).max() == 0.0
     assert b01[(0, 1)] is None
+
+
+def test_two_grid_pressure_laplacian_solve_with_deflated_constants():
+    """The two-grid form of the K_p solve (``CoarseSpace.deflate``): the Galerkin matrix of the
+    Neumann Laplacian is singular with the constants in its kernel; the inverse of
+    ``E + (trace E / n_c^2) 1 1^T`` is its pseudo-inverse on zero-mean right-hand sides, and a few
+    cycles of [correction, sweeps] solve ``K_p x = b`` for a zero-mean ``b`` up to a constant."""
+    from control_amd.coarse import multilinear_coarse_space
+    from oracle import kkt_oracle as ko
+    th = common.stokes_problem(n=8, n_t=3)["th"]
+    K = th.K_p.tocsr()
+    P = multilinear_coarse_space(th.coords_p, (), cells=3)
+    assert np.allclose(np.asarray(P.sum(axis=1)).ravel(), 1.0)
+    co = ko.CoarseSpace(P, 6, deflate=True)
+    E = (P.T @ (K @ P)).toarray()
+    assert abs(E @ np.ones(E.shape[0])).max() < 1e-12             # singular: constants
+    Einv = ko.coarse_inverse(K, co)
+    rng = np.random.default_rng(common.SEED)
+    rc = rng.standard_normal(E.shape[0])
+    rc -= rc.mean()
+    assert np.abs(E @ (Einv @ rc) - rc).max() < 1e-10             # pseudo-inverse on 1-perp
+    x_ref = rng.standard_normal(th.n_p)
+    b = K @ x_ref
+    spec = ko.ChebSpec(8, 0.15, 2.1)
+    spec.coarse = co
+    x = ko._inner_solve(K, spec, b)
+    assert np.linalg.norm(K @ x - b) < 1e-6 * np.linalg.norm(b)
+    e = (x - x.mean()) - (x_ref - x_ref.mean())
+    assert np.linalg.norm(e) < 1e-5 * np.linalg.norm(x_ref)
