@@ -317,10 +317,16 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     auto lap = [&](int slot, unsigned long long count) {
         if (!stamps) return;
         const unsigned long long now = wall_clock64();
+#ifndef KKT_XSTAMPS
         if (tid == 0) {
             sstat[slot] += now - t_mark;
             sstat[slot + 3] += count;
         }
+#else
+        // -DKKT_XSTAMPS: the slots hold the parts of the coarse exchange instead
+        // (scripts/r03_exchange_stamps.py)
+        if (tid == 0 && slot == 0) sstat[3] += count;
+#endif
         t_mark = now;
     };
 
@@ -429,7 +435,9 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
         // the granules of this epoch; only then may anyone publish the next one
         lds_barrier();
         dead = sdead != 0;
+#ifndef KKT_XSTAMPS
         if (stamps && tid == 0) sstat[6] += spins;
+#endif
         lap(0, 1);
     };
 
@@ -806,6 +814,17 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                 }
                 lds_barrier();
                 lap(1, cyc == 0 ? 0 : 1);      // (stamps: the residual step counts as a step)
+#ifdef KKT_XSTAMPS
+                unsigned long long xs_t = wall_clock64();
+                auto xs = [&](int slot) {
+                    const unsigned long long n_ = wall_clock64();
+                    if (tid == 0) sstat[slot] += n_ - xs_t;
+                    xs_t = n_;
+                };
+#define KKT_XS(slot) xs(slot)
+#else
+#define KKT_XS(slot)
+#endif
                 // ---- restriction: partial sums over the own rows for the coarse functions they
                 // touch, a wave per function, lanes stride its list, fixed butterfly
                 ++cepoch;
@@ -835,6 +854,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                     // granules have mostly landed by then.  8 in flight made the compiler spill
                     // ~200 registers in the 512-thread variants.)
                     constexpr int CSL = 4;
+                    KKT_XS(0);      // restriction + publish
                     for (int i = 0; i < A.poll_delay; ++i) __builtin_amdgcn_s_sleep(1);
                     for (int base = 0; base < c_nslots; base += CSL * T) {
                         u32x4 g[CSL];
@@ -881,7 +901,9 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                                     (unsigned long long)g[q].x | ((unsigned long long)g[q].z << 32)));
                         }
                     }
+                    KKT_XS(1);      // polls of this thread
                     lds_barrier();
+                    KKT_XS(2);      // barrier: the slowest thread's polls
                     dead = sdead != 0;
                     for (int j = tid; j < c_nc; j += T) {
                         double a = 0.0;
@@ -889,6 +911,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                         RC[j] = a;
                     }
                     lds_barrier();
+                    KKT_XS(4);      // coarse residual
                     // ---- the coarse functions this tile owns (j = tile, tile + ntiles, ...): a wave
                     // per function, the product published as a granule of the same exchange number
                     const __amdgpu_buffer_rsrc_t re_ = __builtin_amdgcn_make_buffer_rsrc(
@@ -932,6 +955,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                         for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
                         if (lane == 0) publish(re_, tile + i * ntl, a, cepoch);
                     }
+                    KKT_XS(5);      // owned products + publish
                     // ---- the products for the functions the own rows touch, from their owners
                     for (int k0 = 0; k0 < c_nj; k0 += T) {
                         const int k = k0 + tid;
@@ -968,6 +992,7 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                     }
                     lds_barrier();
                     dead = sdead != 0;
+                    KKT_XS(6);      // products polled + barrier
                     // ---- prolongation onto the own rows of the current iterate
                     double *Xc = X + cur * nkp;
 #pragma unroll
