@@ -2233,6 +2233,71 @@ void launch_coarse_correction(hipStream_t s, const CoarseDev &c, const double *e
     hipLaunchKernelGGL(coarse_prolong_kernel, dim3(grid_for(n)), dim3(256), 0, s, c.p_ip, c.p_ix,
                        c.p_v, c.ec, x_in, x_out, n);
 }
+// The same correction for `nb` vectors `vstride` apart (the pressure blocks of the Stokes
+// preconditioner): blockIdx.y picks the vector; every sum in the order of the kernels above, so a
+// block's result equals the one-vector launches bit for bit.  rc / ec: nb * nc doubles each.
+__global__ __launch_bounds__(256) void coarse_restrict_batched_kernel(
+    const int32_t *__restrict__ pt_ip, const int32_t *__restrict__ pt_ix,
+    const double *__restrict__ pt_v, const double *__restrict__ r, double *__restrict__ rc,
+    int nc, int64_t vstride) {
+    __shared__ double sh[256];
+    const int j = blockIdx.x;
+    const double *rb = r + (size_t)blockIdx.y * vstride;
+    double a = 0.0;
+    for (int32_t q = pt_ip[j] + threadIdx.x; q < pt_ip[j + 1]; q += 256)
+        a = __builtin_fma(pt_v[q], rb[pt_ix[q]], a);
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) rc[(size_t)blockIdx.y * nc + j] = sh[0];
+}
+__global__ __launch_bounds__(256) void coarse_dense_batched_kernel(const double *__restrict__ einv,
+                                                                   const double *__restrict__ rc,
+                                                                   double *__restrict__ ec, int nc) {
+    __shared__ double sh[256];
+    const int j = blockIdx.x;
+    const double *row = einv + (size_t)j * nc;
+    const double *rcb = rc + (size_t)blockIdx.y * nc;
+    double a = 0.0;
+    for (int k = threadIdx.x; k < nc; k += 256) a = __builtin_fma(row[k], rcb[k], a);
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ec[(size_t)blockIdx.y * nc + j] = sh[0];
+}
+__global__ void coarse_prolong_batched_kernel(const int32_t *__restrict__ p_ip,
+                                              const int32_t *__restrict__ p_ix,
+                                              const double *__restrict__ p_v,
+                                              const double *__restrict__ ec,
+                                              const double *__restrict__ x_in,
+                                              double *__restrict__ x_out, int64_t n, int nc,
+                                              int64_t vstride) {
+    const double *ecb = ec + (size_t)blockIdx.y * nc;
+    const size_t off = (size_t)blockIdx.y * vstride;
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n;
+         r += (int64_t)gridDim.x * blockDim.x) {
+        double a = 0.0;
+        for (int32_t q = p_ip[r]; q < p_ip[r + 1]; ++q) a = __builtin_fma(p_v[q], ecb[p_ix[q]], a);
+        x_out[off + r] = x_in ? x_in[off + r] + a : a;
+    }
+}
+void launch_coarse_correction_batched(hipStream_t s, const CoarseDev &c, const double *einv,
+                                      const double *r, const double *x_in, double *x_out, int64_t n,
+                                      int nb, int64_t vstride) {
+    if (c.nc <= 0 || nb <= 0) return;
+    hipLaunchKernelGGL(coarse_restrict_batched_kernel, dim3(c.nc, nb), dim3(256), 0, s, c.pt_ip,
+                       c.pt_ix, c.pt_v, r, c.rc, c.nc, vstride);
+    hipLaunchKernelGGL(coarse_dense_batched_kernel, dim3(c.nc, nb), dim3(256), 0, s, einv, c.rc, c.ec,
+                       c.nc);
+    hipLaunchKernelGGL(coarse_prolong_batched_kernel, dim3(grid_for(n, 256, 256), nb), dim3(256), 0, s,
+                       c.p_ip, c.p_ix, c.p_v, c.ec, x_in, x_out, n, c.nc, vstride);
+}
 // set-up: x = column k of P (dense), and one restricted column of A P into E (column-major scratch)
 __global__ void coarse_column_kernel(const int32_t *__restrict__ pt_ip,
                                      const int32_t *__restrict__ pt_ix,

@@ -262,6 +262,10 @@ struct CoarseDev {
 // x_out = x_in + P E^-1 P^T r (x_in may be null or x_out); three launches, fixed summation orders
 void launch_coarse_correction(hipStream_t s, const CoarseDev &c, const double *einv,
                               const double *r, const double *x_in, double *x_out, int64_t n);
+// the same for nb vectors `vstride` apart in one launch per stage (c.rc, c.ec: nb * nc doubles)
+void launch_coarse_correction_batched(hipStream_t s, const CoarseDev &c, const double *einv,
+                                      const double *r, const double *x_in, double *x_out, int64_t n,
+                                      int nb, int64_t vstride);
 void launch_coarse_column(hipStream_t s, const CoarseDev &c, int k, double *x, int64_t n);
 void launch_coarse_restrict(hipStream_t s, const CoarseDev &c, const double *r, double *rc,
                             int stride = 1);

@@ -161,8 +161,8 @@ void StokesPC::build_kp_coarse(const kkt_pc_stokes_desc &d) {
     c.pt_ip = up(tip);
     c.pt_ix = up(tix);
     c.pt_v = up(tv);
-    c.rc = dev_alloc<double>(nc);
-    c.ec = dev_alloc<double>(nc);
+    c.rc = dev_alloc<double>((size_t)nc * 2 * n_);      // one coarse residual per pressure block
+    c.ec = dev_alloc<double>((size_t)nc * 2 * n_);
     owned_.push_back(c.rc);
     owned_.push_back(c.ec);
     // E column by column with the kernels the sweeps use (fixed summation orders)
@@ -488,11 +488,9 @@ void StokesPC::run_chain(Chain &c, const std::vector<ChainStep> &steps) {
     const Bases B{{nullptr, nullptr, nullptr, nullptr}};
     auto launches = [&]() {
         for (const ChainStep &cs : steps) {
-            if (cs.coarse) {
-                for (int k = 0; k < 2 * n_; ++k)
-                    launch_coarse_correction(st, kp_coarse_, kp_einv_, cs.r + (int64_t)k * np_,
-                                             cs.x_in ? cs.x_in + (int64_t)k * np_ : nullptr,
-                                             cs.x_out + (int64_t)k * np_, np_);
+            if (cs.coarse) {      // all pressure blocks: one launch per stage
+                launch_coarse_correction_batched(st, kp_coarse_, kp_einv_, cs.r, cs.x_in, cs.x_out,
+                                                 np_, 2 * n_, np_);
                 continue;
             }
             const RowLaunch &L = cs.L;
