@@ -1551,6 +1551,126 @@ __global__ __launch_bounds__(256) void pc_rows_shared_g(const RowOp *__restrict_
     }
 }
 
+// ---- batched Chebyshev steps, four time levels interleaved (IlOp, kernels.hpp)
+//
+// The batched mass steps are bound by the number of L1 -> L2 requests in flight, and with four
+// levels per thread seven of eight requests of a slot pair were the 8-byte gathers of the four
+// iterates (profiles/r03/spmv_ragged_forms.md).  With the levels of a group interleaved a row's
+// four values are one 32-byte load.  Same fma chain per (row, level) as every other form.
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef KKT_GLOBAL const d4 *gcd4_p;
+typedef KKT_GLOBAL d4 *gd4_p;
+
+template <int KC>
+__global__ __launch_bounds__(256) void pc_rows_il(const IlOp *__restrict__ ops) {
+    constexpr int R = 2, C = 128;
+    const IlOp &op = ops[blockIdx.y];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + wave;
+    if (s >= op.nslices) return;
+    int off0, w;
+    if (op.uniform_w >= 0) {
+        w = op.uniform_w;
+        off0 = s * w;
+    } else {
+        off0 = ((gci_p)op.slice_off)[s];
+        w = ((gci_p)op.slice_off)[s + 1] - off0;
+    }
+    const size_t base = (size_t)off0 * C + (size_t)lane * R;
+    int row[R];
+    {
+        const gci_p perm = (gci_p)op.perm;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int pos = s * C + lane + 64 * q;
+            row[q] = perm ? perm[pos] : (pos < op.nrows ? pos : -1);
+        }
+    }
+    const gcb_p rowmask = (gcb_p)op.rowmask;
+    bool masked[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q)
+        masked[q] = row[q] >= 0 && rowmask != nullptr && rowmask[row[q]] != 0;
+    d4 acc[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+    const gcd4_p x4 = (gcd4_p)op.x;
+    if (x4 != nullptr) {
+        const gci_p colp = (gci_p)op.col + base;
+        const gcd_p vp = (gcd_p)op.vals + base;
+        for (int k0 = 0; k0 < w; k0 += KC) {
+            int c[KC][R];
+            double v[KC][R];
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+                if (k0 + k < w) {
+                    load_cols<R>(colp + (size_t)(k0 + k) * C, c[k]);
+                    load_vals<R, false>(vp + (size_t)(k0 + k) * C, v[k]);
+                }
+            d4 xv[KC][R];
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+                if (k0 + k < w) {
+#pragma unroll
+                    for (int q = 0; q < R; ++q) xv[k][q] = x4[c[k][q]];
+                }
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+                if (k0 + k < w) {
+#pragma unroll
+                    for (int q = 0; q < R; ++q) {
+                        acc[q].x = __builtin_fma(v[k][q], xv[k][q].x, acc[q].x);
+                        acc[q].y = __builtin_fma(v[k][q], xv[k][q].y, acc[q].y);
+                        acc[q].z = __builtin_fma(v[k][q], xv[k][q].z, acc[q].z);
+                        acc[q].w = __builtin_fma(v[k][q], xv[k][q].w, acc[q].w);
+                    }
+                }
+        }
+    }
+    const gcd4_p pkm1 = (gcd4_p)op.pkm1;
+    const gcd_p dinv = (gcd_p)op.dinv;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int r = row[q];
+        if (r < 0) continue;
+        double o[4];
+        if (masked[q]) {
+#pragma unroll
+            for (int l = 0; l < 4; ++l) o[l] = 0.0;
+        } else {
+            const d4 e1 = x4 ? x4[r] : d4{0.0, 0.0, 0.0, 0.0};
+            const d4 e0 = pkm1 ? pkm1[r] : d4{0.0, 0.0, 0.0, 0.0};
+            const double e3 = dinv[r];
+            const double a_[4] = {acc[q].x, acc[q].y, acc[q].z, acc[q].w};
+            const double p0_[4] = {e0.x, e0.y, e0.z, e0.w}, p1_[4] = {e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const double e2 = l < op.nlev ? ((gcd_p)op.b[l])[r] : 0.0;
+                double t = pkm1 ? op.c1 * p0_[l] : 0.0;
+                if (x4) t += op.c2 * p1_[l];
+                t += op.c3 * (e3 * (e2 - a_[l]));
+                o[l] = op.post2[l] * (op.post1[l] * t);
+            }
+        }
+        if (op.out[0] != nullptr) {
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+                if (l < op.nlev) ((gd_p)op.out[l])[r] = o[l];
+        } else {
+            ((gd4_p)op.y)[r] = d4{o[0], o[1], o[2], o[3]};
+        }
+    }
+}
+
+void launch_rowops_il(hipStream_t s, const IlOp *d_ops, int ngroups, int max_slices, int uniform_w) {
+    if (ngroups <= 0 || max_slices <= 0) return;
+    const dim3 grid((max_slices + 3) / 4, ngroups), block(256);
+    if (uniform_w > 0 && uniform_w <= 8)
+        hipLaunchKernelGGL((pc_rows_il<8>), grid, block, 0, s, d_ops);
+    else
+        hipLaunchKernelGGL((pc_rows_il<4>), grid, block, 0, s, d_ops);
+}
+
 // KKT operator apply with shared values ("mode S", time-invariant blocks): block rows whose
 // terms use the same matrices in the same order -- the interior rows of the BE / CN stencils,
 // control.py:2907-2978 -- differ only in the vectors they read and write.  One thread loads the

@@ -64,6 +64,24 @@ void launch_rowops(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, 
                    const Bases &bases, int tag, int uniform_w,
                    const RowOp *h_single = nullptr);
 
+// Batched Chebyshev steps on ONE matrix with the iterates of four time levels interleaved
+// (element (row r, level l) of a group at 4 r + l): a gather serves four levels with one 32-byte
+// load instead of four 8-byte ones.  Right-hand sides and final outputs keep the API layout.
+struct IlOp {
+    const int32_t *col, *slice_off, *perm;
+    const double *vals, *dinv;
+    const uint8_t *rowmask;
+    int32_t nrows, nslices, uniform_w, nlev;   // nlev <= 4 levels in this group
+    const double *b[4];        // right-hand sides of the levels
+    double *out[4];            // out[0] != null: the step writes the levels' outputs (last step)
+    const double *x;           // interleaved p_k (null: first step, no matrix term)
+    const double *pkm1;        // interleaved p_{k-1} or null
+    double *y;                 // interleaved output (when out[0] == null)
+    double c1, c2, c3;
+    double post1[4], post2[4]; // per level (the last step's output scalings)
+};
+void launch_rowops_il(hipStream_t s, const IlOp *d_ops, int ngroups, int max_slices, int uniform_w);
+
 // Batched launch for RowOps that all have ONE term with the same matrix and pattern
 // (uniform width 1..8, R = 2): four time levels per thread.  Returns false if not applicable.
 bool launch_rowops_shared(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, int R,

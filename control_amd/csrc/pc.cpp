@@ -91,6 +91,8 @@ void SchurPC::clear_program() {
         if ((s.kind == PcStep::ROWS || s.kind == PcStep::PROG) && s.rows.d_ops)
             (void)hipFree(s.rows.d_ops);
     for (auto &s : steps_)
+        if (s.d_il) (void)hipFree(s.d_il);
+    for (auto &s : steps_)
         if (s.d_lite) (void)hipFree(s.d_lite);
     for (auto &s : steps_)
         if (s.d_levels) (void)hipFree(s.d_levels);
@@ -873,7 +875,8 @@ void SchurPC::time_stages(kkt_pc_stage_times *out) {
             out->comm_steps += 1;
         } else {
             out->batched_ms += ms;
-            if (s.kind == PcStep::ROWS || s.kind == PcStep::TIME) out->batched_launches += 1;
+            if (s.kind == PcStep::ROWS || s.kind == PcStep::TIME || s.kind == PcStep::ROWS_IL)
+                out->batched_launches += 1;
         }
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
@@ -1479,6 +1482,89 @@ void SchurPC::emit_update_and_solve(Lin upd, const Solve &sv, int its, double em
     sweep_levels_.push_back(lv);
 }
 
+// Batched solves with ONE matrix (the mass solves: every time level the same M): the Chebyshev
+// iterates of four levels interleaved, one IlOp per group and step (kernels.hpp).  Same
+// coefficients and the same fma chain per row and level as emit_solves below.
+bool SchurPC::emit_solves_interleaved(const std::vector<Solve> &sv, int its, double emin,
+                                      double emax) {
+    const char *o = S_.opt("interleave");
+    if (o && o[0] == '0') return false;
+    const size_t m = sv.size();
+    const char *ln = S_.opt("lanes");
+    if (ln && ln[0] != '0') return false;       // (chunks on two streams would share the buffers)
+    for (const Solve &q : sv)
+        if (q.vals != sv[0].vals || q.dinv != sv[0].dinv) return false;
+    const Pattern &P = S_.patterns[m_pat_];
+    const int ng = (int)((m + 3) / 4);
+    const size_t need = (size_t)ng * 4 * (size_t)nx_;
+    if (need > il_cap_) {
+        for (int k = 0; k < 3; ++k) {
+            il_P_[k] = dev_alloc<double>(need + 32);
+            HIPCHK(hipMemsetAsync(il_P_[k], 0, (need + 32) * sizeof(double), S_.stream));
+            owned_.push_back(il_P_[k]);
+        }
+        il_cap_ = need;
+    }
+    const double scale = 2.0 / (emax + emin);
+    const double alpha = 1.0 - scale * emin, mu = 1.0 / alpha, omegaprod = 2.0 / alpha;
+    double c_km1 = 1.0, c_k = mu;
+    auto buf = [&](int step, int g) -> double * {
+        return il_P_[(step - 1) % 3] + (size_t)g * 4 * (size_t)nx_;
+    };
+    for (int step = 1; step <= its; ++step) {
+        double k1 = 0.0, k2 = 0.0, k3 = scale;
+        if (step >= 2) {
+            const double c_kp1 = 2.0 * mu * c_k - c_km1;
+            const double omega = omegaprod * c_k / c_kp1;
+            k1 = 1.0 - omega;
+            k2 = omega;
+            k3 = scale * omega;
+            c_km1 = c_k;
+            c_k = c_kp1;
+        }
+        const bool last = step == its;
+        std::vector<IlOp> ops(ng);
+        for (int g = 0; g < ng; ++g) {
+            IlOp op{};
+            op.col = P.d_col;
+            op.slice_off = P.d_slice_off;
+            op.perm = P.d_perm;
+            op.vals = sv[0].vals;
+            op.dinv = sv[0].dinv;
+            op.rowmask = mask_;
+            op.nrows = (int32_t)nx_;
+            op.nslices = P.nslices;
+            op.uniform_w = P.uniform_w;
+            op.nlev = (int32_t)std::min<size_t>(4, m - (size_t)g * 4);
+            for (int l = 0; l < op.nlev; ++l) {
+                op.b[l] = sv[(size_t)g * 4 + l].b;
+                op.out[l] = last ? sv[(size_t)g * 4 + l].out : nullptr;
+            }
+            op.x = step >= 2 ? buf(step - 1, g) : nullptr;
+            op.pkm1 = step >= 3 ? buf(step - 2, g) : nullptr;
+            op.y = last ? nullptr : buf(step, g);
+            op.c1 = k1;
+            op.c2 = k2;
+            op.c3 = k3;
+            for (int l = 0; l < 4; ++l) {
+                const bool live = last && l < op.nlev;
+                op.post1[l] = live ? sv[(size_t)g * 4 + l].post1 : 1.0;
+                op.post2[l] = live ? sv[(size_t)g * 4 + l].post2 : 1.0;
+            }
+            ops[g] = op;
+        }
+        PcStep s;
+        s.kind = PcStep::ROWS_IL;
+        s.d_il = dev_upload(ops.data(), ops.size());
+        s.il_groups = ng;
+        s.il_slices = P.nslices;
+        s.il_w = P.uniform_w;
+        s.lane = cur_lane_;
+        steps_.push_back(s);
+    }
+    return true;
+}
+
 void SchurPC::emit_solves(const std::vector<Solve> &sv, int its, double emin, double emax,
                           double *const P[3], int64_t pstride, bool first_done,
                           std::vector<TileCoef> *coef_out, double eimag, const Mat *mat) {
@@ -1487,6 +1573,9 @@ void SchurPC::emit_solves(const std::vector<Solve> &sv, int its, double emin, do
         return;
     }
     const size_t m = sv.size();
+    if (m >= 4 && !first_done && its >= 2 && eimag == 0.0 && pstride == nx_ &&
+        emit_solves_interleaved(sv, its, emin, emax))
+        return;
     // a single solve on a final right-hand side is a sweep level without update (the first
     // level of a sweep, the sub-solves of the stationary preconditioner)
     SweepLevel solo;
@@ -1846,6 +1935,9 @@ void SchurPC::replay(size_t first, size_t last) {
                     break;
                 launch_rowops(st, s.rows.d_ops, s.rows.nops, s.rows.max_slices, s.rows.R, B, 1,
                               s.rows.uniform_w, s.rows.single ? &s.rows.h_op : nullptr);
+                break;
+            case PcStep::ROWS_IL:
+                launch_rowops_il(st, s.d_il, s.il_groups, s.il_slices, s.il_w);
                 break;
             case PcStep::TIME:
                 launch_time_transform(st, s.y, s.x, s.tkind, s.n, s.nx, s.lo_halo, s.hi_halo);

@@ -28,7 +28,9 @@ double jacobi_skew_radius(System &S, int pattern, const double *skew_vals, const
                           const uint8_t *rowmask, int max_steps, int *steps_out);
 
 struct PcStep {
-    enum Kind { ROWS, TIME, COPY, COMM, PROG, TILE, EV_RECORD, EV_WAIT, COARSE } kind;
+    enum Kind { ROWS, TIME, COPY, COMM, PROG, TILE, EV_RECORD, EV_WAIT, COARSE, ROWS_IL } kind;
+    IlOp *d_il = nullptr;           // ROWS_IL: one IlOp per group of four time levels
+    int il_groups = 0, il_slices = 0, il_w = 0;
     const double *einv = nullptr;   // COARSE: y = (x or 0) + P E^-1 P^T cr
     const double *cr = nullptr;     // COARSE: the residual that is restricted
     int lane = 0;                   // 0: the system's stream; 1: the side stream
@@ -236,6 +238,8 @@ class SchurPC : public PcBase {
     Mat schur_matrix(const double *base_vals, double c);
     void emit_lin(const std::vector<Lin> &ops);
     void emit_cheb(const std::vector<Cheb> &ops);
+    double *il_P_[3] = {nullptr, nullptr, nullptr};
+    size_t il_cap_ = 0;
     void emit_time(double *y, const double *x, int kind, int n, const double *lo_halo = nullptr,
                    const double *hi_halo = nullptr);
     void emit_comm(const double *send, int dst, double *recv, int src);
@@ -245,6 +249,8 @@ class SchurPC : public PcBase {
         double *out;
         double post1 = 1.0, post2 = 1.0;
     };
+    // batched solves on one matrix with the iterates of four levels interleaved (kernels.hpp IlOp)
+    bool emit_solves_interleaved(const std::vector<Solve> &sv, int its, double emin, double emax);
     void emit_solves(const std::vector<Solve> &sv, int its, double emin, double emax,
                      double *const P[3], int64_t pstride, bool first_done = false,
                      std::vector<TileCoef> *coef_out = nullptr, double eimag = 0.0,

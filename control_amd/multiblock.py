@@ -200,7 +200,7 @@ def _array_of(v, n, nx):
 _ENV_OPTION_KEYS = ("sell_r", "sell_sort", "no_graph", "persistent", "prog_mode", "prog_waves",
                     "prog_steps", "tile_depth", "tile_waves", "lanes", "lane_chunks",
                     "kernarg_ops", "shared_rows", "verbose", "stamps", "tile_poll_delay",
-                    "tile_unfused", "stage_timers", "sell_sigma")
+                    "tile_unfused", "stage_timers", "sell_sigma", "interleave")
 
 
 # ------------------------------------------------------------------ the block system

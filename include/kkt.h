@@ -75,6 +75,8 @@ const char *kkt_last_error(kkt_handle h);
  * preconditioner keys before kkt_set_pc_schur.  Unknown keys are rejected.
  *   "sell_r"      "1" | "2"      rows per lane of the SELL-64R storage (default 2)
  *   "sell_sort"   "0" | "1"      row-sorted storage for ragged structures (default 1)
+ *   "interleave"  "0"            batched mass solves with one vector per time level instead of
+ *                                the iterates of four levels interleaved
  *   "no_graph"    "1"            replay the preconditioner as plain launches, no hipGraph
  *   "persistent"  "0"            time sweeps as one launch per step (no sweep programs)
  *   "prog_mode"   "auto" | "tile" | "dataflow" | "flags" | "w"   sweep-program form (auto, the
