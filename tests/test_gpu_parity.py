@@ -69,8 +69,10 @@ def test_preconditioner_parity_many_workgroups(CN):
     # same arithmetic in the same order: plain launches, the counter form and the data-flow
     # form of the persistent program agree exactly
     # ("w": the opt-in data-flow form for any row width, matrix re-read every phase)
+    # ("interleave": the batched mass solves with one vector per time level instead of the
+    # iterates of four levels interleaved)
     for var, val in (("persistent", "0"), ("prog_mode", "flags"), ("prog_mode", "w"),
-                     ("prog_mode", "dataflow"), ("prog_mode", "tile")):
+                     ("prog_mode", "dataflow"), ("prog_mode", "tile"), ("interleave", "0")):
         other = common.gpu_system(p, options={var: val}).pc_apply(
             x, common.gpu_pc(p, MASS, schur))
         assert np.array_equal(got, other), (var, val)
