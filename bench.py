@@ -437,7 +437,11 @@ def bench_stokes(args, rank, world, local_rank):
     alg = info["bytes_streamed"]          # what the launch must move (index arrays once)
     achieved = alg / (spmv_ms * 1e-3) / 1e9
     th = p["th"]
-    roof = {"kernel": "kkt_spmv_rows (outer Stokes-control operator, this rank's shard)",
+    sw = int(info.get("apply_switched", 0))
+    roof = {"kernel": ("kkt_spmv_rows_ragged (width-switched: a wave runs the body unrolled for its "
+                       "slice's width)" if sw else "kkt_spmv_rows<2,0> (slot loop)") +
+                      f" (outer Stokes-control operator, this rank's shard; {sw} of "
+                      f"{int(info.get('apply_launches', 0))} launches switched)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_named(
                 "traffic_stokes_outer_operator.json", f"stokes2d {n} {n_t} {args.scheme} {args.mode}")

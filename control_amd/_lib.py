@@ -58,7 +58,7 @@ class Info(C.Structure):
                 ("last_op_applies", C.c_int64), ("program_fallbacks", C.c_int64)] + \
                [(n, C.c_int64) for n in
                 ("sweep_form", "sweep_tiles", "sweep_threads", "sweep_depth", "sweep_row_slots",
-                 "sweep_its")]
+                 "sweep_its", "apply_launches", "apply_switched")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -133,6 +133,12 @@ struct NoGran {
 // neighbours, so that after the wait the own-row operands and the first gathers go out
 // back to back.
 constexpr int HOIST_KC = 12;
+#ifndef RAGGED_CASES
+#define RAGGED_CASES KKT_WX(4) KKT_WX(5) KKT_WX(7) KKT_WX(9) KKT_WX(12) KKT_WX(15) KKT_WX(19)
+#endif
+#ifndef RAGGED_CH
+#define RAGGED_CH 8
+#endif
 template <int R>
 struct Hoist {
     static constexpr bool on = false;
@@ -160,12 +166,15 @@ constexpr unsigned GRAN_SPIN_LIMIT = 1u << 20;
 // `terms(t)` yields the t-th SpmvTerm of the op: from the descriptor in memory, or unpacked
 // from a wave-held copy (persistent programs), so that no descriptor array is indexed
 // dynamically in registers.
-template <int R, bool NT, int W, bool COH, class TermFn>
+// FENCE (the width-switched ragged kernel): a scheduling barrier at every chunk boundary keeps the
+// compiler from hoisting the loads of later chunks over earlier ones, so that the allocation is
+// the indices + three chunks whatever W is (unfenced it grows by 14 registers per slot: 250 at
+// W = 16).
+template <int R, bool NT, int W, bool COH, class TermFn, int CH = 8, bool FENCE = false>
 __device__ __forceinline__ void accumulate_exact(const RowOp &op, const TermFn &terms,
                                                  const Bases &bases, size_t base,
                                                  double (&acc)[R]) {
-    constexpr int C = 64 * R;
-    constexpr int CH = 8;                       // slots per register chunk
+    constexpr int C = 64 * R;                   // CH: slots per register chunk
     constexpr int NCH = (W + CH - 1) / CH;
     const gci_p colp = (gci_p)op.col + base;
     int c[W][R];
@@ -183,6 +192,11 @@ __device__ __forceinline__ void accumulate_exact(const RowOp &op, const TermFn &
         const gcd_p x = resolve(tm.x, bases);
         const gcd_p vcur = (gcd_p)tm.vals + base;
         const gcd_p vnext = (t + 1 < nterms) ? (gcd_p)terms(t + 1).vals + base : vcur;
+        // (FENCE) gathers as buffer loads: uniform descriptor of x + one 32-bit byte offset per
+        // gather -- global loads keep a 64-bit offset pair per slot alive across the term loop
+        __amdgpu_buffer_rsrc_t xr;
+        if constexpr (FENCE)
+            xr = __builtin_amdgcn_make_buffer_rsrc((void *)(const double *)x, 0, -1, 0x00020000);
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             constexpr int dummy = 0;
@@ -196,7 +210,14 @@ __device__ __forceinline__ void accumulate_exact(const RowOp &op, const TermFn &
 #pragma unroll
                     for (int q = 0; q < R; ++q) {
                         v[k][q] = vn[k][q];
-                        xv[k][q] = ldv<COH>(x + c[k0 + k][q]);
+                        if constexpr (FENCE) {
+                            typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                            const u2 g = __builtin_amdgcn_raw_buffer_load_b64(
+                                xr, (unsigned)c[k0 + k][q] << 3, 0, 0);
+                            xv[k][q] = __hiloint2double((int)g.y, (int)g.x);
+                        } else {
+                            xv[k][q] = ldv<COH>(x + c[k0 + k][q]);
+                        }
                     }
                 }
             // next chunk's (or next term's first chunk's) values go in flight now
@@ -217,6 +238,7 @@ __device__ __forceinline__ void accumulate_exact(const RowOp &op, const TermFn &
 #pragma unroll
                     for (int q = 0; q < R; ++q) acc[q] = __builtin_fma(v[k][q], xv[k][q], acc[q]);
                 }
+            if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -450,10 +472,28 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const TermFn &terms
 #pragma unroll
     for (int q = 0; q < R; ++q) acc[q] = 0.0;
     if (op.nterms > 0) {
-        if constexpr (WFIX > 0)
+        if constexpr (WFIX > 0) {
             accumulate_exact<R, NT, WFIX, COH>(op, terms, bases, base, acc);
-        else
+        } else if constexpr (WFIX == -1) {
+            static_assert(NT && !COH && R == 2 && !GranT::on && !GranT::hoist, "operator apply only");
+            // Ragged structures in the operator apply (P2: rows of 9 / 19, Q2: 9 / 15 / 25, the
+            // rectangular blocks of the Stokes system: 4 / 7): a wave is one slice, so its width
+            // is wave-uniform and the wave can run the body unrolled for exactly that width --
+            // the indices of the slice stay in registers for all terms and the next chunk of
+            // matrix values is in flight under the gathers, as in the fixed-width launches.  The
+            // slot loop below loads (index, value, gather) per slot and term: two dependent round
+            // trips per four slots, during which no value load is outstanding -- the value stream
+            // and the rest added up instead of overlapping (profiles/r03/spmv_ragged_forms.md).
+            // Every row keeps its fma chain (term-major, CSR order): results do not change.
+            switch (__builtin_amdgcn_readfirstlane(w)) {
+#define KKT_WX(n) case n: accumulate_exact<R, NT, n, COH, TermFn, RAGGED_CH, true>(op, terms, bases, base, acc); break;
+                RAGGED_CASES
+#undef KKT_WX
+                default: accumulate_generic<R, NT, COH>(op, terms, bases, base, w, acc, gran);
+            }
+        } else {
             accumulate_generic<R, NT, COH>(op, terms, bases, base, w, acc, gran);
+        }
     }
 
     const gd_p y = (gd_p)resolve(op.y, bases);
@@ -530,6 +570,15 @@ __global__ __launch_bounds__(256) void kkt_spmv_rows(const RowOp *__restrict__ o
     const RowOp &op = ops[blockIdx.y];
     rowops_body<R, true, WFIX, false>(op, [&](int t) { return op.t[t]; }, bases,
                                       blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+// Ragged structures (WFIX = -1: a wave picks the body unrolled for its slice's width).  The
+// allocation is the widest body's; held to two waves per SIMD, where the fixed-width launches
+// of 15-wide rows (64^3 P1) run as well.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void kkt_spmv_rows_ragged(const RowOp *__restrict__ ops, const Bases bases) {
+    const RowOp &op = ops[blockIdx.y];
+    rowops_body<2, true, -1, false>(op, [&](int t) { return op.t[t]; }, bases,
+                                    blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 template <int R, int WFIX>
 __global__ __launch_bounds__(256) void pc_rows(const RowOp *__restrict__ ops,
@@ -1806,7 +1855,22 @@ void launch_rowops(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, 
         KKT_W(1) KKT_W(2) KKT_W(3) KKT_W(4) KKT_W(5) KKT_W(6) KKT_W(7) KKT_W(8)
         KKT_W(9) KKT_W(10) KKT_W(11) KKT_W(12) KKT_W(13) KKT_W(14) KKT_W(15) KKT_W(16)
 #undef KKT_W
+        case UNIFORM_W_SWITCH:   // ragged, most slots in slices of a width the switch kernel unrolls
+            if (tag == 0) {
+                hipLaunchKernelGGL(kkt_spmv_rows_ragged, grid, dim3(256), 0, s, d_ops, bases);
+                break;
+            }
+            [[fallthrough]];
         default: launch_one<2, 0>(s, grid, d_ops, bases, tag, h_single); break;
+    }
+}
+
+bool ragged_switch_width(int w) {
+    switch (w) {
+#define KKT_WX(n) case n: return true;
+        RAGGED_CASES
+#undef KKT_WX
+        default: return false;
     }
 }
 

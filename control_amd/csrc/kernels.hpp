@@ -63,6 +63,11 @@ struct RowOp {
 void launch_rowops(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, int R,
                    const Bases &bases, int tag, int uniform_w,
                    const RowOp *h_single = nullptr);
+// uniform_w of a launch of ragged structures whose slots lie (>= 75 %) in slices of a width
+// ragged_switch_width() accepts: the operator apply then runs kkt_spmv_rows_ragged, where a wave
+// picks the body unrolled for its slice's width (other widths: the slot loop, in the same kernel)
+constexpr int UNIFORM_W_SWITCH = -2;
+bool ragged_switch_width(int w);
 
 // Batched Chebyshev steps on ONE matrix with the iterates of four time levels interleaved
 // (element (row r, level l) of a group at 4 r + l): a gather serves four levels with one 32-byte

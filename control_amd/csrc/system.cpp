@@ -714,7 +714,36 @@ void System::finalize() {
                 }
             }
         }
+        // ragged launch: which kernel (kernels.hpp, UNIFORM_W_SWITCH)
+        {
+            const char *rs = opt("ragged_switch");
+            if (L.uniform_w == -1 && L.R == 2 && !(rs && rs[0] == '0')) {
+                int64_t slots = 0, covered = 0;
+                for (const RowOp &op : waves[w]) {
+                    if (op.nterms == 0) continue;
+                    for (const Pattern &P : patterns) {
+                        if (P.d_col != op.col) continue;
+                        for (int s = 0; s < P.nslices; ++s) {
+                            const int ws = P.h_slice_off[s + 1] - P.h_slice_off[s];
+                            slots += (int64_t)ws * op.nterms;
+                            if (ragged_switch_width(ws)) covered += (int64_t)ws * op.nterms;
+                        }
+                        break;
+                    }
+                }
+                if (slots > 0 && covered * 4 >= slots * 3) {
+                    L.uniform_w = UNIFORM_W_SWITCH;
+                    info.apply_switched++;
+                }
+                if (opt("verbose"))
+                    std::fprintf(stderr, "[kkt] operator apply, launch %zu: ragged, %.1f %% of the "
+                                 "slots in slices of an unrolled width -> %s\n", w,
+                                 slots ? 100.0 * covered / slots : 0.0,
+                                 L.uniform_w == UNIFORM_W_SWITCH ? "width-switched kernel" : "slot loop");
+            }
+        }
         L.d_ops = dev_upload(waves[w].data(), waves[w].size());
+        info.apply_launches++;
         apply_launches.push_back(L);
     }
     h_apply_ops = waves;

@@ -374,6 +374,9 @@ typedef struct kkt_info {
                                    program, 3 tile program */
     int64_t sweep_tiles, sweep_threads, sweep_depth, sweep_row_slots;   /* tile program plan */
     int64_t sweep_its;          /* Chebyshev degree of the sub-solves (given or derived) */
+    int64_t apply_launches;     /* kernel launches of one kkt_apply (block rows only) */
+    int64_t apply_switched;     /* ... of which run the width-switched kernel for ragged
+                                   structures (P2 / Stokes blocks; option "ragged_switch") */
 } kkt_info;
 int kkt_get_info(kkt_handle h, kkt_info *info);
 

@@ -237,6 +237,27 @@ def test_row_sorted_storage_is_bit_identical():
     assert infos[1]["bytes_device_values"] < 0.85 * infos[0]["bytes_device_values"]
 
 
+@pytest.mark.parametrize("CN", [False, True])
+def test_width_switched_ragged_operator_is_bit_identical(CN):
+    """Ragged structures in the operator apply (P2 velocity blocks: slices of 19 / 9 entries, the
+    rectangular Stokes blocks: 7 / 4) run kkt_spmv_rows_ragged, where a wave picks the body
+    unrolled for its slice's width; slices of any other width take the slot loop inside the same
+    kernel.  Every row keeps its fma chain: the result equals the slot-loop kernel's
+    ("ragged_switch" = "0") bit for bit, and the oracle's to round-off.  32 x 32 Taylor-Hood:
+    interior windows of full 19- and 9-wide slices, boundary windows of other widths."""
+    p = common.stokes_problem(n=32, n_t=4, CN=CN)
+    outs = []
+    for flag in ("1", "0"):
+        outer, _ = common.stokes_gpu(p, options={"ragged_switch": flag})
+        info = outer.info()
+        assert info["apply_switched"] == (info["apply_launches"] if flag == "1" else 0)
+        x = common.rng_vector(info["n_local"])
+        outs.append(outer.mult(x))
+    assert np.array_equal(outs[0], outs[1])
+    osys = common.stokes_oracle(p)[0]
+    assert common.rel_err(outs[0], osys.mult(x)) < 1e-13
+
+
 def test_mid_size_mesh_long_sweep_program_matches_plain_launches():
     """A mesh with more than 1 024 slices (401^2 nodes: 1 257) runs the data-flow sweep program
     with multi-wave workgroups; with 4-wave workgroups, two to a CU, programs of about 1 000
