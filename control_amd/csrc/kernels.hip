@@ -175,6 +175,9 @@ __device__ __forceinline__ void accumulate_exact(const RowOp &op, const TermFn &
                                                  const Bases &bases, size_t base,
                                                  double (&acc)[R]) {
     constexpr int C = 64 * R;                   // CH: slots per register chunk
+    // (buffer gathers in the fixed-width launches too -- 138 -> 124 registers at width 7, four
+    // waves per SIMD instead of three -- change nothing: 0.279-0.283 ms either way on cfg 2)
+    constexpr bool BUFG = FENCE;
     constexpr int NCH = (W + CH - 1) / CH;
     const gci_p colp = (gci_p)op.col + base;
     int c[W][R];
@@ -195,7 +198,7 @@ __device__ __forceinline__ void accumulate_exact(const RowOp &op, const TermFn &
         // (FENCE) gathers as buffer loads: uniform descriptor of x + one 32-bit byte offset per
         // gather -- global loads keep a 64-bit offset pair per slot alive across the term loop
         __amdgpu_buffer_rsrc_t xr;
-        if constexpr (FENCE)
+        if constexpr (BUFG)
             xr = __builtin_amdgcn_make_buffer_rsrc((void *)(const double *)x, 0, -1, 0x00020000);
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
@@ -210,7 +213,7 @@ __device__ __forceinline__ void accumulate_exact(const RowOp &op, const TermFn &
 #pragma unroll
                     for (int q = 0; q < R; ++q) {
                         v[k][q] = vn[k][q];
-                        if constexpr (FENCE) {
+                        if constexpr (BUFG) {
                             typedef unsigned u2 __attribute__((ext_vector_type(2)));
                             const u2 g = __builtin_amdgcn_raw_buffer_load_b64(
                                 xr, (unsigned)c[k0 + k][q] << 3, 0, 0);
