@@ -170,7 +170,11 @@ constexpr unsigned GRAN_SPIN_LIMIT = 1u << 20;
 // compiler from hoisting the loads of later chunks over earlier ones, so that the allocation is
 // the indices + three chunks whatever W is (unfenced it grows by 14 registers per slot: 250 at
 // W = 16).
-template <int R, bool NT, int W, bool COH, class TermFn, int CH = 8, bool FENCE = false>
+// NSEG > 1 (the width-switched kernel, slices of NSEG * W slots: the B blocks of the Stokes
+// system are 2 x 19 wide): a slice is worked off in NSEG segments of W slots per term -- same fma
+// chain (term-major, slots ascending), the W index registers re-loaded per (term, segment).
+template <int R, bool NT, int W, bool COH, class TermFn, int CH = 8, bool FENCE = false,
+          int NSEG = 1>
 __device__ __forceinline__ void accumulate_exact(const RowOp &op, const TermFn &terms,
                                                  const Bases &bases, size_t base,
                                                  double (&acc)[R]) {
@@ -183,7 +187,8 @@ __device__ __forceinline__ void accumulate_exact(const RowOp &op, const TermFn &
     int c[W][R];
 #pragma unroll
     for (int k = 0; k < W; ++k) load_cols<R>(colp + (size_t)k * C, c[k]);
-    const int nterms = op.nterms;
+    const int nterms = op.nterms * NSEG;        // (term, segment) pairs, term-major
+    constexpr size_t SEG = (size_t)W * C;
     double vn[CH][R];                           // values of the next (term, chunk)
     {
         const gcd_p vp = (gcd_p)terms(0).vals + base;
@@ -191,10 +196,19 @@ __device__ __forceinline__ void accumulate_exact(const RowOp &op, const TermFn &
         for (int k = 0; k < (W < CH ? W : CH); ++k) load_vals<R, NT>(vp + (size_t)k * C, vn[k]);
     }
     for (int t = 0; t < nterms; ++t) {
-        const SpmvTerm tm = terms(t);
+        const SpmvTerm tm = terms(t / NSEG);
         const gcd_p x = resolve(tm.x, bases);
-        const gcd_p vcur = (gcd_p)tm.vals + base;
-        const gcd_p vnext = (t + 1 < nterms) ? (gcd_p)terms(t + 1).vals + base : vcur;
+        const gcd_p vcur = (gcd_p)tm.vals + base + (size_t)(t % NSEG) * SEG;
+        const gcd_p vnext = (t + 1 < nterms) ? (gcd_p)terms((t + 1) / NSEG).vals + base +
+                                                   (size_t)((t + 1) % NSEG) * SEG
+                                             : vcur;
+        if constexpr (NSEG > 1) {
+            if (t > 0) {
+#pragma unroll
+                for (int k = 0; k < W; ++k)
+                    load_cols<R>(colp + (size_t)(t % NSEG) * SEG + (size_t)k * C, c[k]);
+            }
+        }
         // (FENCE) gathers as buffer loads: uniform descriptor of x + one 32-bit byte offset per
         // gather -- global loads keep a 64-bit offset pair per slot alive across the term loop
         __amdgpu_buffer_rsrc_t xr;
@@ -492,6 +506,8 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const TermFn &terms
 #define KKT_WX(n) case n: accumulate_exact<R, NT, n, COH, TermFn, RAGGED_CH, true>(op, terms, bases, base, acc); break;
                 RAGGED_CASES
 #undef KKT_WX
+                case 24: accumulate_exact<R, NT, 12, COH, TermFn, RAGGED_CH, true, 2>(op, terms, bases, base, acc); break;
+                case 38: accumulate_exact<R, NT, 19, COH, TermFn, RAGGED_CH, true, 2>(op, terms, bases, base, acc); break;
                 default: accumulate_generic<R, NT, COH>(op, terms, bases, base, w, acc, gran);
             }
         } else {
@@ -581,7 +597,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void kkt_spmv_rows_ragged(const RowOp *__restrict__ ops, const Bases bases) {
     const RowOp &op = ops[blockIdx.y];
     rowops_body<2, true, -1, false>(op, [&](int t) { return op.t[t]; }, bases,
-                                    blockIdx.x * 4 + (threadIdx.x >> 6));
+                                    blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
 }
 template <int R, int WFIX>
 __global__ __launch_bounds__(256) void pc_rows(const RowOp *__restrict__ ops,
@@ -1863,6 +1879,16 @@ void launch_rowops(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, 
                 hipLaunchKernelGGL(kkt_spmv_rows_ragged, grid, dim3(256), 0, s, d_ops, bases);
                 break;
             }
+            launch_one<2, 0>(s, grid, d_ops, bases, tag, h_single);
+            break;
+        case UNIFORM_W_SWITCH_1WAVE:
+            if (tag == 0) {
+                // one wave per workgroup: the slices of a window differ in width (19, 19, 12, 9, ...),
+                // and a four-wave workgroup holds its registers until its widest slice is done
+                hipLaunchKernelGGL(kkt_spmv_rows_ragged, dim3(max_slices, nops), dim3(64), 0, s,
+                                   d_ops, bases);
+                break;
+            }
             [[fallthrough]];
         default: launch_one<2, 0>(s, grid, d_ops, bases, tag, h_single); break;
     }
@@ -1870,6 +1896,7 @@ void launch_rowops(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, 
 
 bool ragged_switch_width(int w) {
     switch (w) {
+        case 24: case 38: return true;
 #define KKT_WX(n) case n: return true;
         RAGGED_CASES
 #undef KKT_WX
@@ -2209,6 +2236,8 @@ __global__ void const_sums_kernel(const ConstJob *__restrict__ jobs, int njobs,
     const ConstJob j = jobs[blockIdx.x];
     const double *xb = (blockIdx.y == 0 ? a : b) + j.off;
     double acc = 0.0;
+    // one chain per thread, eight loads in flight (the additions keep their order)
+#pragma unroll 8
     for (int64_t r = threadIdx.x; r < j.nx; r += 256) acc += xb[r];
     sh[threadIdx.x] = acc;
     __syncthreads();
@@ -2219,15 +2248,16 @@ __global__ void const_sums_kernel(const ConstJob *__restrict__ jobs, int njobs,
     if (threadIdx.x == 0) sums[blockIdx.y * njobs + blockIdx.x] = sh[0];
 }
 __global__ void const_shift_kernel(const ConstJob *__restrict__ jobs, int njobs,
-                                   double *__restrict__ y, const double *__restrict__ sums,
+                                   double *y, const double *src, const double *__restrict__ sums,
                                    int second) {
     const ConstJob j = jobs[blockIdx.y];
     const double s1 = j.c1 * sums[blockIdx.y];
     const double s2 = second ? (second == 2 ? j.c2_alpha : j.c2_one) * sums[njobs + blockIdx.y] : 0.0;
     double *yb = y + j.off;
+    const double *sb = src + j.off;
     for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < j.nx;
          r += (int64_t)gridDim.x * blockDim.x) {
-        double v = yb[r] + s1;
+        double v = sb[r] + s1;
         if (second) v += s2;
         yb[r] = v;
     }
@@ -2238,7 +2268,17 @@ void launch_const_correct(hipStream_t s, const ConstJob *d_jobs, int njobs, int6
     hipLaunchKernelGGL(const_sums_kernel, dim3(njobs, second ? 2 : 1), dim3(256), 0, s, d_jobs,
                        njobs, y, b, sums);
     hipLaunchKernelGGL(const_shift_kernel, dim3(grid_for(max_nx, 256, 64), njobs), dim3(256), 0,
-                       s, d_jobs, njobs, y, sums, second);
+                       s, d_jobs, njobs, y, y, sums, second);
+}
+// xc_j = x_j - mean(x_j) on the ConstantNullspace blocks only, out of place (the other blocks of xc
+// are not written: the operator's terms read them from x itself)
+void launch_const_center(hipStream_t s, const ConstJob *d_jobs, int njobs, int64_t max_nx,
+                         const double *x, double *xc, double *sums) {
+    if (njobs <= 0) return;
+    hipLaunchKernelGGL(const_sums_kernel, dim3(njobs, 1), dim3(256), 0, s, d_jobs, njobs, x,
+                       (const double *)nullptr, sums);
+    hipLaunchKernelGGL(const_shift_kernel, dim3(grid_for(max_nx, 256, 64), njobs), dim3(256), 0,
+                       s, d_jobs, njobs, xc, x, sums, 0);
 }
 
 // -------------------------------------------------------------------------- reductions

@@ -67,6 +67,11 @@ void launch_rowops(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, 
 // ragged_switch_width() accepts: the operator apply then runs kkt_spmv_rows_ragged, where a wave
 // picks the body unrolled for its slice's width (other widths: the slot loop, in the same kernel)
 constexpr int UNIFORM_W_SWITCH = -2;
+// the same with one wave per workgroup, for launches of wide slices (mean width >= 10): the slices
+// of a sort window differ in width (P2: 19, 19, 12, 9, 9, ...) and a four-wave workgroup holds its
+// registers until its widest slice is done (P2: 0.565 -> 0.510 ms); narrow slices (the B^T blocks
+// of the Stokes system: 4 / 5 / 7) move too few bytes per wave to be dispatched one by one
+constexpr int UNIFORM_W_SWITCH_1WAVE = -3;
 bool ragged_switch_width(int w);
 
 // Batched Chebyshev steps on ONE matrix with the iterates of four time levels interleaved
@@ -259,6 +264,8 @@ void launch_block_shift(hipStream_t s, double *y, const double *sums, double coe
 struct ConstJob { int64_t off, nx; double c1, c2_one, c2_alpha; };
 void launch_const_correct(hipStream_t s, const ConstJob *d_jobs, int njobs, int64_t max_nx,
                           double *y, const double *b, int second, double *sums);
+void launch_const_center(hipStream_t s, const ConstJob *d_jobs, int njobs, int64_t max_nx,
+                         const double *x, double *xc, double *sums);
 void launch_block_sums(hipStream_t s, const double *x, double *sums, int n, int64_t nx,
                        double *scratch);
 

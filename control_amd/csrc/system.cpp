@@ -504,6 +504,7 @@ void System::finalize() {
 
     any_const_ns = false;
     for (auto &ns : nullspaces) any_const_ns |= ns.kind == 2;
+    if (any_const_ns && !d_xc) d_xc = new_vec();
     fused_row_masks = !CN;
 
     // ---- row plan: one RowOp per (row, run of same-pattern terms), chained by accumulation
@@ -588,7 +589,13 @@ void System::finalize() {
                             std::make_tuple((int)w, pl.waves.size() > w ? (int)pl.waves[w].size() : 0, nt);
                         term_in_halo_plan[std::make_tuple(b->q, b->i, b->j)] = row_halo;
                         const int lj = level_of(b->j);
-                        if (!sharded || (lj >= lo && lj < hi)) {
+                        if (!sharded && nullspaces[col0 ? b->j : n0 + b->j].kind == 2) {
+                            // column block with a ConstantNullspace: the term reads x - mean(x)
+                            // from the handle's own buffer (System::apply centres these blocks
+                            // only; every other block is read from the caller's x)
+                            op.t[nt].x = VRef{(int64_t)(uintptr_t)(
+                                d_xc + local_offset(col0 ? 0 : 1, local_of(b->j))), 0, 0};
+                        } else if (!sharded || (lj >= lo && lj < hi)) {
                             op.t[nt].x = vref(1, local_offset(col0 ? 0 : 1, local_of(b->j)));
                         } else if (families == 1) {
                             op.t[nt].x = lj < lo ? vref(3, 0)    // halo below (block lo-1)
@@ -718,7 +725,7 @@ void System::finalize() {
         {
             const char *rs = opt("ragged_switch");
             if (L.uniform_w == -1 && L.R == 2 && !(rs && rs[0] == '0')) {
-                int64_t slots = 0, covered = 0;
+                int64_t slots = 0, covered = 0, nsl = 0;
                 for (const RowOp &op : waves[w]) {
                     if (op.nterms == 0) continue;
                     for (const Pattern &P : patterns) {
@@ -726,20 +733,23 @@ void System::finalize() {
                         for (int s = 0; s < P.nslices; ++s) {
                             const int ws = P.h_slice_off[s + 1] - P.h_slice_off[s];
                             slots += (int64_t)ws * op.nterms;
+                            nsl += op.nterms;
                             if (ragged_switch_width(ws)) covered += (int64_t)ws * op.nterms;
                         }
                         break;
                     }
                 }
                 if (slots > 0 && covered * 4 >= slots * 3) {
-                    L.uniform_w = UNIFORM_W_SWITCH;
+                    L.uniform_w = slots >= 10 * nsl ? UNIFORM_W_SWITCH_1WAVE : UNIFORM_W_SWITCH;
                     info.apply_switched++;
                 }
                 if (opt("verbose"))
                     std::fprintf(stderr, "[kkt] operator apply, launch %zu: ragged, %.1f %% of the "
                                  "slots in slices of an unrolled width -> %s\n", w,
                                  slots ? 100.0 * covered / slots : 0.0,
-                                 L.uniform_w == UNIFORM_W_SWITCH ? "width-switched kernel" : "slot loop");
+                                 L.uniform_w == UNIFORM_W_SWITCH ? "width-switched kernel" :
+                                 L.uniform_w == UNIFORM_W_SWITCH_1WAVE ? "width-switched kernel, one "
+                                 "wave per workgroup" : "slot loop");
             }
         }
         L.d_ops = dev_upload(waves[w].data(), waves[w].size());
@@ -789,7 +799,6 @@ void System::finalize() {
         d_mask_jobs_one = dev_upload(jobs.data(), jobs.size());
     }
     if (any_const_ns) {
-        d_xc = new_vec();
         std::vector<ConstJob> cj;
         for (int var = 0; var < 2; ++var) {
             const int nloc = var == 0 ? n0_loc : n1_loc;
@@ -887,8 +896,12 @@ void System::apply(const double *d_x, double *d_y) {
     info.last_op_applies++;
     const double *xin = d_x;
     const int nb = n0_loc + n1_loc;
-    if (any_const_ns) {
-        // x_c = x - mean(x) on ConstantNullspace blocks (preconditioner.py:145-146, 384-393)
+    if (any_const_ns && !sharded) {
+        // x_c = x - mean(x) on ConstantNullspace blocks (preconditioner.py:145-146, 384-393):
+        // only those blocks are written to d_xc, and only the terms on them read it
+        launch_const_center(stream, d_const_jobs, n_const_jobs, const_max_nx, d_x, d_xc, d_sums);
+    } else if (any_const_ns) {
+        // time shards: the halo exchange sends blocks of x_c, so all of it is formed
         launch_copy(stream, d_xc, d_x, n_local);
         launch_const_correct(stream, d_const_jobs, n_const_jobs, const_max_nx, d_xc, nullptr, 0,
                              d_sums);
