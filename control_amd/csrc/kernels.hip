@@ -594,10 +594,22 @@ __global__ __launch_bounds__(256) void kkt_spmv_rows(const RowOp *__restrict__ o
 // allocation is the widest body's; held to two waves per SIMD, where the fixed-width launches
 // of 15-wide rows (64^3 P1) run as well.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void kkt_spmv_rows_ragged(const RowOp *__restrict__ ops, const Bases bases) {
+void kkt_spmv_rows_ragged(const RowOp *__restrict__ ops, const Bases bases, const int per_xcd) {
     const RowOp &op = ops[blockIdx.y];
+    // per_xcd > 0 (gridDim.x = 8 * per_xcd): workgroups are dealt round-robin over the 8 XCDs, so
+    // workgroup x of a block row runs on XCD x % 8; XCD k takes the k-th contiguous eighth of the
+    // block row's workgroups -- its L2 then holds an eighth of the index array and of every x
+    // window instead of (nearly) all of both
+    // (an eighth of THIS block row's workgroups: the block rows of a launch differ in size)
+    const int wpw = (int)(blockDim.x >> 6);
+    int wg = (int)blockIdx.x;
+    if (per_xcd > 0) {
+        const int per = ((op.nslices + wpw - 1) / wpw + 7) >> 3;
+        if ((int)(blockIdx.x >> 3) >= per) return;
+        wg = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    }
     rowops_body<2, true, -1, false>(op, [&](int t) { return op.t[t]; }, bases,
-                                    blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+                                    wg * wpw + (int)(threadIdx.x >> 6));
 }
 template <int R, int WFIX>
 __global__ __launch_bounds__(256) void pc_rows(const RowOp *__restrict__ ops,
@@ -1860,6 +1872,9 @@ static void launch_one(hipStream_t s, dim3 grid, const RowOp *d_ops, const Bases
         hipLaunchKernelGGL((pc_rows<R, WFIX>), grid, dim3(256), 0, s, d_ops, bases);
 }
 
+static bool g_ragged_xcd = true;
+void set_ragged_xcd(bool on) { g_ragged_xcd = on; }
+
 void launch_rowops(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, int R,
                    const Bases &bases, int tag, int uniform_w, const RowOp *h_single) {
     if (nops <= 0 || max_slices <= 0) return;
@@ -1876,7 +1891,9 @@ void launch_rowops(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, 
 #undef KKT_W
         case UNIFORM_W_SWITCH:   // ragged, most slots in slices of a width the switch kernel unrolls
             if (tag == 0) {
-                hipLaunchKernelGGL(kkt_spmv_rows_ragged, grid, dim3(256), 0, s, d_ops, bases);
+                const int per = g_ragged_xcd ? ((max_slices + 3) / 4 + 7) / 8 : 0;
+                hipLaunchKernelGGL(kkt_spmv_rows_ragged, dim3(per ? 8 * per : grid.x, nops),
+                                   dim3(256), 0, s, d_ops, bases, per);
                 break;
             }
             launch_one<2, 0>(s, grid, d_ops, bases, tag, h_single);
@@ -1885,8 +1902,9 @@ void launch_rowops(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, 
             if (tag == 0) {
                 // one wave per workgroup: the slices of a window differ in width (19, 19, 12, 9, ...),
                 // and a four-wave workgroup holds its registers until its widest slice is done
-                hipLaunchKernelGGL(kkt_spmv_rows_ragged, dim3(max_slices, nops), dim3(64), 0, s,
-                                   d_ops, bases);
+                const int per = g_ragged_xcd ? (max_slices + 7) / 8 : 0;
+                hipLaunchKernelGGL(kkt_spmv_rows_ragged, dim3(per ? 8 * per : max_slices, nops),
+                                   dim3(64), 0, s, d_ops, bases, per);
                 break;
             }
             [[fallthrough]];

@@ -73,6 +73,11 @@ constexpr int UNIFORM_W_SWITCH = -2;
 // of the Stokes system: 4 / 5 / 7) move too few bytes per wave to be dispatched one by one
 constexpr int UNIFORM_W_SWITCH_1WAVE = -3;
 bool ragged_switch_width(int w);
+// XCD-aware workgroup order in the ragged kernel (default on; option "ragged_xcd" = "0": dispatch
+// order).  P2 0.507 -> 0.46-0.48 ms, Stokes outer operator 0.778 -> 0.729 ms.  (On the fixed-width
+// P1 launches the same relabelling was slower, profiles/DIARY_r01_r02.md 8.1b: their traffic is
+// 1.1 x the bytes already; the ragged launches fetched 1.4 x.)
+void set_ragged_xcd(bool on);
 
 // Batched Chebyshev steps on ONE matrix with the iterates of four time levels interleaved
 // (element (row r, level l) of a group at 4 r + l): a gather serves four levels with one 32-byte

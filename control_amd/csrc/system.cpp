@@ -926,6 +926,10 @@ void System::apply(const double *d_x, double *d_y) {
         rows_out = d_tmp_y;
     }
     Bases B{{xin, rows_out, d_halo_x0_lo, d_halo_x1_hi}};
+    {
+        const char *rx = opt("ragged_xcd");
+        set_ragged_xcd(!(rx && rx[0] == '0'));
+    }
     auto launch = [&](const RowLaunch &L) {
         if (L.ngroups > 0 &&
             launch_rowops_grouped(stream, L.d_ops, L.d_groups, L.ngroups, L.max_slices, L.R,
