@@ -247,13 +247,13 @@ def test_width_switched_ragged_operator_is_bit_identical(CN):
     interior windows of full 19- and 9-wide slices, boundary windows of other widths."""
     p = common.stokes_problem(n=32, n_t=4, CN=CN)
     outs = []
-    for flag in ("1", "0"):
-        outer, _ = common.stokes_gpu(p, options={"ragged_switch": flag})
+    for flag, xcd in (("1", "1"), ("0", "1"), ("1", "0")):   # "ragged_xcd": XCD-aware workgroup order
+        outer, _ = common.stokes_gpu(p, options={"ragged_switch": flag, "ragged_xcd": xcd})
         info = outer.info()
         assert info["apply_switched"] == (info["apply_launches"] if flag == "1" else 0)
         x = common.rng_vector(info["n_local"])
         outs.append(outer.mult(x))
-    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     osys = common.stokes_oracle(p)[0]
     assert common.rel_err(outs[0], osys.mult(x)) < 1e-13
 
