@@ -600,6 +600,9 @@ def main():
                     help="skip the side leg on BASELINE configs[3] (3-D heat 64^3, n_t = 128)")
     ap.add_argument("--no-tile-coordinates", action="store_true",
                     help="do not pass the dof coordinates as the tiling hint of the sweep programs")
+    ap.add_argument("--lib-option", action="append", default=[], metavar="KEY=VALUE",
+                    help="kkt_set_option on the heat-control handle (A/B runs of kernel forms, e.g. "
+                         "apply_xcd=1); printed in config")
     ap.add_argument("--only-spmv", action="store_true",
                     help="time the KKT SpMV only (counter-collection passes)")
     ap.add_argument("--launch-timeout", type=float, default=1700.0,
@@ -697,8 +700,10 @@ def measure_heat(args, rank, world, local_rank, tts):
     # with KKT_TRANSPORT=gloo); production: one GPU per local rank
     device = int(os.environ.get("KKT_DEVICE", local_rank))
     t_setup = time.perf_counter()
+    lib_options = dict(kv.split("=", 1) for kv in getattr(args, "lib_option", []) or [])
     gsys = common.gpu_system(p, device=device, comm=comm, share_values=p["share_values"],
-                             tile_coordinates=not args.no_tile_coordinates)
+                             tile_coordinates=not args.no_tile_coordinates,
+                             **({"options": lib_options} if lib_options else {}))
     lib, h = gsys._lib, gsys.handle
     if not args.only_spmv:       # (counter-collection passes of the operator need no preconditioner)
         gpc = common.gpu_pc(p, p["mass"], p["schur"], coarse=p.get("coarse"))

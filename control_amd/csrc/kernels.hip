@@ -583,12 +583,23 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const TermFn &terms
 
 // Two entry points over one body so that profiles separate the KKT operator apply (the
 // roofline kernel of bench.py) from the many small block-row steps of the preconditioner.
+// XCD-aware order (xcd != 0; gridDim.x a multiple of 8): workgroup x of a block row runs on XCD
+// x % 8, which takes the k-th contiguous eighth of THIS block row's workgroups (eighths differ by
+// at most one workgroup).  Returns -1 for a workgroup beyond its eighth.
+__device__ __forceinline__ int xcd_workgroup(int nwg, int xcd) {
+    if (!xcd) return (int)blockIdx.x;
+    const int k = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
+    const int lo = (k * nwg) >> 3, hi = ((k + 1) * nwg) >> 3;
+    return j < hi - lo ? lo + j : -1;
+}
 template <int R, int WFIX>
 __global__ __launch_bounds__(256) void kkt_spmv_rows(const RowOp *__restrict__ ops,
-                                                     const Bases bases) {
+                                                     const Bases bases, const int xcd) {
     const RowOp &op = ops[blockIdx.y];
+    const int wg = xcd_workgroup((op.nslices + 3) >> 2, xcd);
+    if (wg < 0) return;
     rowops_body<R, true, WFIX, false>(op, [&](int t) { return op.t[t]; }, bases,
-                                      blockIdx.x * 4 + (threadIdx.x >> 6));
+                                      wg * 4 + (threadIdx.x >> 6));
 }
 // Ragged structures (WFIX = -1: a wave picks the body unrolled for its slice's width).  The
 // allocation is the widest body's; held to two waves per SIMD, where the fixed-width launches
@@ -602,12 +613,8 @@ void kkt_spmv_rows_ragged(const RowOp *__restrict__ ops, const Bases bases, cons
     // window instead of (nearly) all of both
     // (an eighth of THIS block row's workgroups: the block rows of a launch differ in size)
     const int wpw = (int)(blockDim.x >> 6);
-    int wg = (int)blockIdx.x;
-    if (per_xcd > 0) {
-        const int per = ((op.nslices + wpw - 1) / wpw + 7) >> 3;
-        if ((int)(blockIdx.x >> 3) >= per) return;
-        wg = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    }
+    const int wg = xcd_workgroup((op.nslices + wpw - 1) / wpw, per_xcd);
+    if (wg < 0) return;
     rowops_body<2, true, -1, false>(op, [&](int t) { return op.t[t]; }, bases,
                                     wg * wpw + (int)(threadIdx.x >> 6));
 }
@@ -1861,13 +1868,17 @@ bool launch_rowops_shared(hipStream_t s, const RowOp *d_ops, int nops, int max_s
     }
 }
 
+static bool g_apply_xcd = false;
+void set_apply_xcd(bool on) { g_apply_xcd = on; }
 template <int R, int WFIX>
 static void launch_one(hipStream_t s, dim3 grid, const RowOp *d_ops, const Bases &bases, int tag,
                        const RowOp *h_single) {
     if (h_single && tag != 0)
         hipLaunchKernelGGL((pc_row_step<R, WFIX>), grid, dim3(256), 0, s, *h_single, bases);
     else if (tag == 0)
-        hipLaunchKernelGGL((kkt_spmv_rows<R, WFIX>), grid, dim3(256), 0, s, d_ops, bases);
+        hipLaunchKernelGGL((kkt_spmv_rows<R, WFIX>),
+                           dim3(g_apply_xcd ? (grid.x + 7) / 8 * 8 : grid.x, grid.y), dim3(256), 0, s,
+                           d_ops, bases, g_apply_xcd ? 1 : 0);
     else
         hipLaunchKernelGGL((pc_rows<R, WFIX>), grid, dim3(256), 0, s, d_ops, bases);
 }

@@ -929,6 +929,8 @@ void System::apply(const double *d_x, double *d_y) {
     {
         const char *rx = opt("ragged_xcd");
         set_ragged_xcd(!(rx && rx[0] == '0'));
+        const char *ax = opt("apply_xcd");
+        set_apply_xcd(ax && ax[0] == '1');
     }
     auto launch = [&](const RowLaunch &L) {
         if (L.ngroups > 0 &&
