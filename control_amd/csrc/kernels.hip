@@ -510,6 +510,16 @@ __device__ __forceinline__ void rowops_body(const RowOp &op, const TermFn &terms
                 case 38: accumulate_exact<R, NT, 19, COH, TermFn, RAGGED_CH, true, 2>(op, terms, bases, base, acc); break;
                 default: accumulate_generic<R, NT, COH>(op, terms, bases, base, w, acc, gran);
             }
+        } else if constexpr (WFIX == -2) {
+            // the same for launches whose slices are at most 7 wide (the B^T terms of the Stokes
+            // system: 4 / 5 / 7, one term): few bytes per wave, so the waves resident count -- the
+            // allocation is the 7-wide body's instead of the 19-wide one's
+            switch (__builtin_amdgcn_readfirstlane(w)) {
+#define KKT_WX(n) case n: accumulate_exact<R, NT, n, COH, TermFn, RAGGED_CH, true>(op, terms, bases, base, acc); break;
+                KKT_WX(3) KKT_WX(4) KKT_WX(5) KKT_WX(6) KKT_WX(7)
+#undef KKT_WX
+                default: accumulate_generic<R, NT, COH>(op, terms, bases, base, w, acc, gran);
+            }
         } else {
             accumulate_generic<R, NT, COH>(op, terms, bases, base, w, acc, gran);
         }
@@ -617,6 +627,14 @@ void kkt_spmv_rows_ragged(const RowOp *__restrict__ ops, const Bases bases, cons
     if (wg < 0) return;
     rowops_body<2, true, -1, false>(op, [&](int t) { return op.t[t]; }, bases,
                                     wg * wpw + (int)(threadIdx.x >> 6));
+}
+__global__ __launch_bounds__(256) void kkt_spmv_rows_ragged_narrow(const RowOp *__restrict__ ops,
+                                                                   const Bases bases, const int per_xcd) {
+    const RowOp &op = ops[blockIdx.y];
+    const int wg = xcd_workgroup((op.nslices + 3) >> 2, per_xcd);
+    if (wg < 0) return;
+    rowops_body<2, true, -2, false>(op, [&](int t) { return op.t[t]; }, bases,
+                                    wg * 4 + (int)(threadIdx.x >> 6));
 }
 template <int R, int WFIX>
 __global__ __launch_bounds__(256) void pc_rows(const RowOp *__restrict__ ops,
@@ -1900,6 +1918,15 @@ void launch_rowops(hipStream_t s, const RowOp *d_ops, int nops, int max_slices, 
         KKT_W(1) KKT_W(2) KKT_W(3) KKT_W(4) KKT_W(5) KKT_W(6) KKT_W(7) KKT_W(8)
         KKT_W(9) KKT_W(10) KKT_W(11) KKT_W(12) KKT_W(13) KKT_W(14) KKT_W(15) KKT_W(16)
 #undef KKT_W
+        case UNIFORM_W_SWITCH_NARROW:
+            if (tag == 0) {
+                const int per = g_ragged_xcd ? ((max_slices + 3) / 4 + 7) / 8 : 0;
+                hipLaunchKernelGGL(kkt_spmv_rows_ragged_narrow, dim3(per ? 8 * per : grid.x, nops),
+                                   dim3(256), 0, s, d_ops, bases, per);
+                break;
+            }
+            launch_one<2, 0>(s, grid, d_ops, bases, tag, h_single);
+            break;
         case UNIFORM_W_SWITCH:   // ragged, most slots in slices of a width the switch kernel unrolls
             if (tag == 0) {
                 const int per = g_ragged_xcd ? ((max_slices + 3) / 4 + 7) / 8 : 0;

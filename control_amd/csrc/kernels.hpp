@@ -72,6 +72,9 @@ constexpr int UNIFORM_W_SWITCH = -2;
 // registers until its widest slice is done (P2: 0.565 -> 0.510 ms); narrow slices (the B^T blocks
 // of the Stokes system: 4 / 5 / 7) move too few bytes per wave to be dispatched one by one
 constexpr int UNIFORM_W_SWITCH_1WAVE = -3;
+// every slice of the launch at most 7 wide: kkt_spmv_rows_ragged_narrow (bodies 3 .. 7 only, so
+// that more waves are resident)
+constexpr int UNIFORM_W_SWITCH_NARROW = -4;
 bool ragged_switch_width(int w);
 // XCD-aware workgroup order in the ragged kernel (default on; option "ragged_xcd" = "0": dispatch
 // order).  P2 0.507 -> 0.46-0.48 ms, Stokes outer operator 0.778 -> 0.729 ms.  (On the fixed-width

@@ -726,6 +726,7 @@ void System::finalize() {
             const char *rs = opt("ragged_switch");
             if (L.uniform_w == -1 && L.R == 2 && !(rs && rs[0] == '0')) {
                 int64_t slots = 0, covered = 0, nsl = 0;
+                int widest = 0;
                 for (const RowOp &op : waves[w]) {
                     if (op.nterms == 0) continue;
                     for (const Pattern &P : patterns) {
@@ -734,12 +735,16 @@ void System::finalize() {
                             const int ws = P.h_slice_off[s + 1] - P.h_slice_off[s];
                             slots += (int64_t)ws * op.nterms;
                             nsl += op.nterms;
+                            widest = std::max(widest, ws);
                             if (ragged_switch_width(ws)) covered += (int64_t)ws * op.nterms;
                         }
                         break;
                     }
                 }
-                if (slots > 0 && covered * 4 >= slots * 3) {
+                if (slots > 0 && widest <= 7) {
+                    L.uniform_w = UNIFORM_W_SWITCH_NARROW;
+                    info.apply_switched++;
+                } else if (slots > 0 && covered * 4 >= slots * 3) {
                     L.uniform_w = slots >= 10 * nsl ? UNIFORM_W_SWITCH_1WAVE : UNIFORM_W_SWITCH;
                     info.apply_switched++;
                 }
@@ -749,7 +754,9 @@ void System::finalize() {
                                  slots ? 100.0 * covered / slots : 0.0,
                                  L.uniform_w == UNIFORM_W_SWITCH ? "width-switched kernel" :
                                  L.uniform_w == UNIFORM_W_SWITCH_1WAVE ? "width-switched kernel, one "
-                                 "wave per workgroup" : "slot loop");
+                                 "wave per workgroup" :
+                                 L.uniform_w == UNIFORM_W_SWITCH_NARROW ? "width-switched kernel for "
+                                 "narrow slices" : "slot loop");
             }
         }
         L.d_ops = dev_upload(waves[w].data(), waves[w].size());
