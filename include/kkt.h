@@ -75,6 +75,11 @@ const char *kkt_last_error(kkt_handle h);
  * preconditioner keys before kkt_set_pc_schur.  Unknown keys are rejected.
  *   "sell_r"      "1" | "2"      rows per lane of the SELL-64R storage (default 2)
  *   "sell_sort"   "0" | "1"      row-sorted storage for ragged structures (default 1)
+ *   "ragged_switch" "0"          operator apply on ragged structures (P2 / Stokes blocks) with the
+ *                                slot loop instead of the width-switched kernel
+ *   "ragged_xcd"  "0"            ... in dispatch order instead of the XCD-aware workgroup order
+ *   "apply_xcd"   "1"            XCD-aware order for the fixed-width operator launches too
+ *                                (measured slower; off)
  *   "interleave"  "0"            batched mass solves with one vector per time level instead of
  *                                the iterates of four levels interleaved
  *   "no_graph"    "1"            replay the preconditioner as plain launches, no hipGraph
