@@ -38,6 +38,9 @@ if os.path.exists(os.path.join(SRC, "spmv_forms.jsonl")):          # scripts/r03
 f = glob.glob(os.path.join(SRC, "stokes_op", "**", "*kernel_stats.csv"), recursive=True)
 if f:
     shutil.copy(f[0], os.path.join(DST, "stokes_operator_kernel_stats.csv"))
+f = glob.glob(os.path.join(SRC, "stokes_leg", "**", "*kernel_stats.csv"), recursive=True)
+if f:
+    shutil.copy(f[0], os.path.join(DST, "stokes_leg_kernel_stats.csv"))
 for kind in ("kernel_stats", "domain_stats"):
     f = glob.glob(os.path.join(SRC, "heat", "**", f"*{kind}.csv"), recursive=True)
     if f:

@@ -17,6 +17,9 @@ KKT_NO_GRAPH=1 timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $o/stokes_o
 echo "stokes op kernel stats rc=$?"
 timeout -k 10 400 python bench.py --workload stokes2d --steps 10 --warmup 2 > $o/bench_stokes2d.json 2> $o/stokes.err
 echo "stokes rc=$?"
+# kernel stats of the whole Stokes leg (plain launches: rocprofv3 and the captured applications, see r03_profiles.sh)
+KKT_NO_GRAPH=1 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $o/stokes_leg -o s --output-format csv -- python3 bench.py --workload stokes2d --steps 5 --warmup 1 --tts-max-it 1 > $o/stokes_leg.json 2> $o/stokes_leg.err
+echo "stokes leg kernel stats rc=$?"
 for opt in "" "--options ragged_xcd=0" "--options ragged_switch=0"; do
   echo "forms $opt" >> $o/spmv_forms.jsonl
   timeout -k 10 300 python scripts/r03_spmv_forms.py --cases p1,q2,p2,stokes $opt >> $o/spmv_forms.jsonl 2>> $o/spmv_forms.err
