@@ -189,6 +189,13 @@ struct TileCoarseDev {
     uint32_t cg_bytes;
     unsigned long long *eg[2];    // ... and of the products (E^-1 r_c)_j, 2 words per coarse function
     uint32_t eg_bytes;
+    // Columns of row j of (P^T A P)^-1 that can be non-zero: [e_lo[j], e_hi[j]), e_lo a multiple of
+    // 64.  P^T A P is block diagonal over the connected components of its graph (a vector-valued
+    // space: one block per component of the field) and so is its inverse -- Gauss-Jordan with
+    // partial pivoting leaves exact zeros outside the blocks -- so the owned products run over the
+    // row's block only and the rows kept in LDS are `ew` = max (e_hi - e_lo) long.
+    const int32_t *e_lo, *e_hi;
+    int32_t ew;
 };
 constexpr int TILE_COARSE_SLOTS = 8;   // partial-sum slots polled per thread, at most
 struct TileArgs {
@@ -219,7 +226,8 @@ int tile_sweep_max_rpt(int W, int threads);   // most row slots per thread of an
 bool tile_sweep_fuses_update(int W, int max_terms);   // update terms of any level of the run
 size_t tile_sweep_lds_bytes(int nk_pad, int its, int coarse_nc = 0, int coarse_nslots = 0,
                             int coarse_jmax = 0, int coarse_nr_max = 0,
-                            int coarse_einv_rows = 0);   // rows of the coarse inverse kept in LDS
+                            int coarse_einv_rows = 0,
+                            int coarse_einv_width = 0);   // rows of the coarse inverse kept in LDS
 // workgroups of `threads` that are certainly co-resident (one per CU)
 int tile_sweep_max_tiles(int W, int rpt, int threads, size_t lds_bytes, int hslots,
                          bool coarse = false);

@@ -385,7 +385,8 @@ bool SchurPC::prepare_tiles() {
             const size_t lds_c = tile_sweep_lds_bytes(tp.nk_pad, max_its, h_tile_coarse_.nc,
                                                       h_tile_coarse_.nslots, h_tile_coarse_.jmax,
                                                       cache ? h_tile_coarse_.nr_max : 0,
-                                                      cache == 2 ? h_tile_coarse_.nown : 0);
+                                                      cache == 2 ? h_tile_coarse_.nown : 0,
+                                                      h_tile_coarse_.ew);
             if (lds_c <= 150 * 1024 &&
                 tp.ntiles <= tile_sweep_max_tiles(tp.W, tp.rpt, threads, lds_c, tp.hslots, true)) {
                 tile_coarse_ok_ = true;
@@ -509,6 +510,50 @@ bool SchurPC::build_tile_coarse() {
     D.cg_bytes = (uint32_t)((size_t)nslots * 16);
     D.eg_bytes = (uint32_t)((size_t)nc * 16);
     D.nown = (nc + nt - 1) / nt;
+    {
+        // Diagonal blocks of P^T A P (kernels.hpp, TileCoarseDev): coarse functions i and j are
+        // coupled when P[r, i], A[r, s] and P[s, j] are stored entries for some rows r, s --
+        // structure only, so the blocks hold for every matrix on this pattern (the Dirichlet
+        // rows and columns only remove couplings).  Union-find over the coarse functions.
+        const Pattern &P = S_.patterns[m_pat_];
+        std::vector<int32_t> uf(nc);
+        for (int j = 0; j < nc; ++j) uf[j] = j;
+        auto find = [&](int32_t a) {
+            while (uf[a] != a) a = uf[a] = uf[uf[a]];
+            return a;
+        };
+        for (int64_t r = 0; r < P.nrows; ++r) {
+            if (p_indptr_[r + 1] == p_indptr_[r]) continue;
+            const int32_t a = find(p_indices_[p_indptr_[r]]);
+            auto join = [&](int64_t row) {
+                for (int32_t q = p_indptr_[row]; q < p_indptr_[row + 1]; ++q) {
+                    const int32_t b = find(p_indices_[q]);
+                    if (b != a) uf[b] = a;
+                }
+            };
+            join(r);
+            for (int32_t q = P.h_indptr[r]; q < P.h_indptr[r + 1]; ++q) join(P.h_indices[q]);
+        }
+        std::vector<int32_t> cmin(nc, nc), cmax(nc, -1), e_lo(nc), e_hi(nc);
+        for (int j = 0; j < nc; ++j) {
+            const int32_t c = find(j);
+            cmin[c] = std::min(cmin[c], (int32_t)j);
+            cmax[c] = std::max(cmax[c], (int32_t)j);
+        }
+        int ew = 64;
+        for (int j = 0; j < nc; ++j) {
+            const int32_t c = find(j);
+            e_lo[j] = cmin[c] & ~63;
+            e_hi[j] = cmax[c] + 1;
+            ew = std::max(ew, e_hi[j] - e_lo[j]);
+        }
+        D.e_lo = up(e_lo);
+        D.e_hi = up(e_hi);
+        D.ew = ew;
+        if (S_.opt("verbose"))
+            std::fprintf(stderr, "[kkt] coarse inverse: rows of at most %d of %d columns (diagonal "
+                         "blocks of P^T A P)\n", ew, nc);
+    }
     for (int i = 0; i < 2; ++i) {
         D.cg[i] = dev_alloc<unsigned long long>((size_t)nslots * 2);
         HIPCHK(hipMemset(D.cg[i], 0, D.cg_bytes));
@@ -549,7 +594,8 @@ bool SchurPC::fuse_tile_run(size_t k, size_t e, std::vector<PcStep> &out) {
                                                           h_tile_coarse_.cache_lists
                                                               ? h_tile_coarse_.nr_max : 0,
                                                           h_tile_coarse_.cache_einv
-                                                              ? h_tile_coarse_.nown : 0)
+                                                              ? h_tile_coarse_.nown : 0,
+                                                          h_tile_coarse_.ew)
                                    : tile_sweep_lds_bytes(tile_plan_.nk_pad, its);
         if (need > tile_lds_checked_) {
             if (need > 150 * 1024 ||

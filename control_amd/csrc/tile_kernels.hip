@@ -253,8 +253,17 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
     bool c_einv_cache = false;
     const void *einv_key = nullptr;
     const int c_nown = COARSE ? (c_nc > tile ? (c_nc - tile + (int)gridDim.x - 1) / (int)gridDim.x : 0) : 0;
+    // the column range of the first row this wave owns (row j over its diagonal block only,
+    // kernels.hpp TileCoarseDev), read once: few tiles own more rows than they have waves
+    int c_lo0 = 0, c_hi0 = 0, c_ew = 0;
     if constexpr (COARSE) {
         const TileCoarseDev *cd = A.coarse;
+        c_ew = cd->ew;
+        if ((int)(threadIdx.x >> 6) < c_nown) {
+            const int j0 = tile + (int)(threadIdx.x >> 6) * (int)gridDim.x;
+            c_lo0 = cd->e_lo[j0];
+            c_hi0 = cd->e_hi[j0];
+        }
         c_cached = cd->cache_lists != 0;
         const int nrm = c_cached ? cd->nr_max : 0;
         RWc = EC + c_jmax;
@@ -917,37 +926,47 @@ __global__ __launch_bounds__(TMAX) void pc_tile_sweep(
                     const __amdgpu_buffer_rsrc_t re_ = __builtin_amdgcn_make_buffer_rsrc(
                         (void *)cd->eg[cepoch & 1], 0, (int)cd->eg_bytes, 0x00020000);
                     const int ntl = (int)gridDim.x;
+                    // (row j only over the columns of its diagonal block, [e_lo[j], e_hi[j]) with
+                    // e_lo a multiple of 64: a lane keeps the columns it had, the terms left out
+                    // are exact zeros -- kernels.hpp, TileCoarseDev)
+                    const gci_p elo = (gci_p)cd->e_lo, ehi = (gci_p)cd->e_hi;
                     if (c_einv_cache && (const void *)einv != einv_key) {
                         // (the iterates' barrier above ordered every earlier read of EINVc)
                         for (int i = wave; i < c_nown; i += nwaves) {
-                            const gcd_p row = einv + (size_t)(tile + i * ntl) * c_nc;
-                            for (int q = lane; q < c_nc; q += 64) EINVc[(size_t)i * c_nc + q] = row[q];
+                            const int j = tile + i * ntl;
+                            const int lo = i == wave ? c_lo0 : elo[j], hi = i == wave ? c_hi0 : ehi[j];
+                            const gcd_p row = einv + (size_t)j * c_nc;
+                            for (int q = lo + lane; q < hi; q += 64)
+                                EINVc[(size_t)i * c_ew + (q - lo)] = row[q];
                         }
                         einv_key = (const void *)einv;
                         // (a wave reads back only the row it wrote: no barrier needed)
                     }
                     for (int i = wave; i < c_nown; i += nwaves) {
                         double a = 0.0;
+                        const int j = tile + i * ntl;
+                        const int lo = i == wave ? c_lo0 : elo[j], hi = i == wave ? c_hi0 : ehi[j];
                         if (c_einv_cache) {
                             // (reading six entries ahead of the fma chain was slower: 128 its/s
                             // against 133 -- the 1 024-thread variant has no registers to spare)
-                            const double *row = EINVc + (size_t)i * c_nc;
-                            for (int q = lane; q < c_nc; q += 64) a = __builtin_fma(row[q], RC[q], a);
+                            const double *row = EINVc + (size_t)i * c_ew;
+                            for (int q = lo + lane; q < hi; q += 64)
+                                a = __builtin_fma(row[q - lo], RC[q], a);
                         } else {
                             // rows from L2: eight loads of a lane in flight before the first fma
-                            const gcd_p row = einv + (size_t)(tile + i * ntl) * c_nc;
+                            const gcd_p row = einv + (size_t)j * c_nc;
                             constexpr int EU = 8;
-                            for (int q0 = lane; q0 < c_nc; q0 += 64 * EU) {
+                            for (int q0 = lo + lane; q0 < hi; q0 += 64 * EU) {
                                 double rv[EU];
 #pragma unroll
                                 for (int u = 0; u < EU; ++u) {
                                     const int q = q0 + 64 * u;
-                                    rv[u] = q < c_nc ? row[q] : 0.0;
+                                    rv[u] = q < hi ? row[q] : 0.0;
                                 }
 #pragma unroll
                                 for (int u = 0; u < EU; ++u) {
                                     const int q = q0 + 64 * u;
-                                    if (q < c_nc) a = __builtin_fma(rv[u], RC[q], a);
+                                    if (q < hi) a = __builtin_fma(rv[u], RC[q], a);
                                 }
                             }
                         }
@@ -1293,11 +1312,12 @@ bool tile_sweep_fuses_update(int W, int max_terms) {
 }
 
 size_t tile_sweep_lds_bytes(int nk_pad, int its, int coarse_nc, int coarse_nslots, int coarse_jmax,
-                            int coarse_nr_max, int coarse_einv_rows) {
+                            int coarse_nr_max, int coarse_einv_rows, int coarse_einv_width) {
     if (coarse_nc > 0 && coarse_einv_rows > 0)
         return tile_sweep_lds_bytes(nk_pad, its, coarse_nc, coarse_nslots, coarse_jmax,
                                     coarse_nr_max, 0) +
-               (size_t)coarse_einv_rows * coarse_nc * sizeof(double) + 8;
+               (size_t)coarse_einv_rows * (coarse_einv_width > 0 ? coarse_einv_width : coarse_nc) *
+                   sizeof(double) + 8;
     if (coarse_nc > 0)
         return (2 * (size_t)nk_pad + 3 * (size_t)std::max(1, its) + 1 + (size_t)coarse_nslots +
                 (size_t)coarse_nc + (size_t)coarse_jmax + 2 * (size_t)coarse_nr_max) * sizeof(double) +
@@ -1373,7 +1393,8 @@ void launch_tile_sweep(hipStream_t s, const TileArgs &a, const TileLevel *d_leve
     const size_t lds = h_coarse ? tile_sweep_lds_bytes(a.nk_pad, a.its, h_coarse->nc,
                                                        h_coarse->nslots, h_coarse->jmax,
                                                        h_coarse->cache_lists ? h_coarse->nr_max : 0,
-                                                       h_coarse->cache_einv ? h_coarse->nown : 0)
+                                                       h_coarse->cache_einv ? h_coarse->nown : 0,
+                                                       h_coarse->ew)
                                 : tile_sweep_lds_bytes(a.nk_pad, a.its);
     tile_fn f = pick_tile(a.W, a.rpt, threads, a.fused_update != 0, a.hslots, h_coarse != nullptr);
     if (!f) throw TileLaunchError{"tile sweep program: no kernel variant for this plan"};
