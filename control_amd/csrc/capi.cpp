@@ -70,7 +70,7 @@ int kkt_set_option(kkt_handle h, const char *key, const char *value) {
                                       "prog_waves", "prog_steps", "tile_depth", "tile_waves",
                                       "lanes", "lane_chunks", "kernarg_ops", "shared_rows",
                                       "verbose", "stamps", "tile_poll_delay", "tile_unfused",
-                                      "debug_drop_handoff", "stage_timers", "sell_sigma", "ragged_switch", "ragged_xcd", "apply_xcd",
+                                      "debug_drop_handoff", "stage_timers", "sell_sigma", "ragged_switch", "ragged_xcd", "apply_xcd", "pc_xcd",
                                       "interleave"};
         if (!key || !value) fail(KKT_ERR_ARG, "null option");
         bool ok = false;

@@ -81,7 +81,8 @@ bool ragged_switch_width(int w);
 // P1 launches the same relabelling was slower, profiles/DIARY_r01_r02.md 8.1b: their traffic is
 // 1.1 x the bytes already; the ragged launches fetched 1.4 x.)
 void set_ragged_xcd(bool on);
-void set_apply_xcd(bool on);    // the same order for the fixed-width operator launches (option "apply_xcd")
+void set_apply_xcd(bool on);
+void set_pc_xcd(bool on);       // ... and for the batched preconditioner steps (option "pc_xcd")    // the same order for the fixed-width operator launches (option "apply_xcd")
 
 // Batched Chebyshev steps on ONE matrix with the iterates of four time levels interleaved
 // (element (row r, level l) of a group at 4 r + l): a gather serves four levels with one 32-byte

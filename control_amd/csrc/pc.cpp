@@ -1955,6 +1955,10 @@ void SchurPC::emit_comm(const double *send, int dst, double *recv, int src) {
 }
 
 void SchurPC::replay(size_t first, size_t last) {
+    {
+        const char *px = S_.opt("pc_xcd");
+        set_pc_xcd(!(px && px[0] == '0'));
+    }
     Bases B{{nullptr, nullptr, nullptr, nullptr}};
     if (n_events_ > 0 && !side_) {
         HIPCHK(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));

@@ -80,6 +80,8 @@ const char *kkt_last_error(kkt_handle h);
  *   "ragged_xcd"  "0"            ... in dispatch order instead of the XCD-aware workgroup order
  *   "apply_xcd"   "1"            XCD-aware order for the fixed-width operator launches too
  *                                (measured slower; off)
+ *   "pc_xcd"      "0"            batched preconditioner steps in dispatch order instead of the
+ *                                XCD-aware workgroup order
  *   "interleave"  "0"            batched mass solves with one vector per time level instead of
  *                                the iterates of four levels interleaved
  *   "no_graph"    "1"            replay the preconditioner as plain launches, no hipGraph
