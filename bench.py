@@ -318,8 +318,9 @@ def bench_stokes(args, rank, world, local_rank):
         kp_coarse = (multilinear_coarse_space(p["th"].coords_p, (),
                                               cells=max(2, n // max(1, args.kp_coarse_cell))),
                      args.kp_coarse_cycles)
+    lib_options = dict(kv.split("=", 1) for kv in getattr(args, "lib_option", []) or []) or None
     outer, gpc = common.stokes_gpu(p, specs, comm=comm, device=device, coarse=coarse,
-                                   kp_coarse=kp_coarse)
+                                   kp_coarse=kp_coarse, options=lib_options)
     lib, h = outer._lib, outer.handle
     if not args.only_spmv:
         outer._set_pc(gpc)
