@@ -2684,6 +2684,25 @@ __global__ __launch_bounds__(256) void gj_eliminate_kernel(double *__restrict__ 
         m[(size_t)r * n + col] -= f * m[(size_t)c * n + col];
     }
 }
+// Set-up check of the tile program's column ranges (TileCoarseDev::e_lo / e_hi): flag = 1 if row j
+// of a coarse inverse has a non-zero entry outside [lo_j, hi_j).
+__global__ __launch_bounds__(256) void einv_outside_kernel(const double *__restrict__ einv, int nc,
+                                                           const int32_t *__restrict__ lo,
+                                                           const int32_t *__restrict__ hi,
+                                                           unsigned *__restrict__ flag) {
+    const int j = blockIdx.x;
+    const double *row = einv + (size_t)j * nc;
+    const int l = lo[j], h = hi[j];
+    bool bad = false;
+    for (int q = threadIdx.x; q < nc; q += 256)
+        if ((q < l || q >= h) && row[q] != 0.0) bad = true;
+    if (bad) atomicOr(flag, 1u);
+}
+void launch_einv_outside(hipStream_t s, const double *einv, int nc, const int32_t *lo,
+                         const int32_t *hi, unsigned *flag) {
+    if (nc > 0) hipLaunchKernelGGL(einv_outside_kernel, dim3(nc), dim3(256), 0, s, einv, nc, lo, hi, flag);
+}
+
 __global__ void gj_identity_kernel(double *__restrict__ inv, int n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n * n;
          i += (size_t)gridDim.x * blockDim.x)

@@ -314,6 +314,8 @@ void launch_coarse_correction(hipStream_t s, const CoarseDev &c, const double *e
 void launch_coarse_correction_batched(hipStream_t s, const CoarseDev &c, const double *einv,
                                       const double *r, const double *x_in, double *x_out, int64_t n,
                                       int nb, int64_t vstride);
+void launch_einv_outside(hipStream_t s, const double *einv, int nc, const int32_t *lo,
+                         const int32_t *hi, unsigned *flag);
 void launch_coarse_column(hipStream_t s, const CoarseDev &c, int k, double *x, int64_t n);
 void launch_coarse_restrict(hipStream_t s, const CoarseDev &c, const double *r, double *rc,
                             int stride = 1);

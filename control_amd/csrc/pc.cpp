@@ -550,6 +550,27 @@ bool SchurPC::build_tile_coarse() {
         D.e_lo = up(e_lo);
         D.e_hi = up(e_hi);
         D.ew = ew;
+        if (ew < nc) {
+            // belt and braces: every inverse formed so far must be zero outside these ranges
+            // (exact zeros: elimination never touches an entry outside a block); else full rows
+            unsigned *d_flag = dev_alloc<unsigned>(1);
+            HIPCHK(hipMemsetAsync(d_flag, 0, sizeof(unsigned), S_.stream));
+            for (const double *inv : einv_owned_)
+                launch_einv_outside(S_.stream, inv, nc, D.e_lo, D.e_hi, d_flag);
+            unsigned bad = 0;
+            HIPCHK(hipMemcpyAsync(&bad, d_flag, sizeof bad, hipMemcpyDeviceToHost, S_.stream));
+            HIPCHK(hipStreamSynchronize(S_.stream));
+            HIPCHK(hipFree(d_flag));
+            if (bad) {
+                std::fprintf(stderr, "[kkt] coarse inverse: entries outside the diagonal blocks of its "
+                             "structure -- the tile program applies full rows\n");
+                std::fill(e_lo.begin(), e_lo.end(), 0);
+                std::fill(e_hi.begin(), e_hi.end(), nc);
+                D.e_lo = up(e_lo);
+                D.e_hi = up(e_hi);
+                D.ew = nc;
+            }
+        }
         if (S_.opt("verbose"))
             std::fprintf(stderr, "[kkt] coarse inverse: rows of at most %d of %d columns (diagonal "
                          "blocks of P^T A P)\n", ew, nc);
